@@ -1,0 +1,146 @@
+/*
+ * pifusion.h -- C ABI of libpifusion.so, the MI355X-native drop-in for the
+ * Map2DFusion multi-band hot path of Immortalqx/pi-slam-fusion.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the reference tree).  Plain pointers and sizes only; no C++/torch types.
+ * All int-returning calls follow the reference's bool convention: 1 = ok,
+ * 0 = failed (message on stderr), never throw, never abort.
+ *
+ * Poses are 7 doubles in the reference's SE3 stream order
+ * `x y z qx qy qz qw` (GSLAM/GSLAM/core/SE3.h:112-117); a pose is
+ * camera-to-world exactly as handed to Map2D::feed (Map2DFusion/Map2D.h:91).
+ */
+#ifndef PIFUSION_H
+#define PIFUSION_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ELE_PIXELS 256            /* Map2DFusion/Map2D.h:35 ELE_PIXELS */
+
+/* Map2D::Map2DType, Map2DFusion/Map2D.h:83 */
+enum { PF_TYPE_NONE = 0, PF_TYPE_CPU = 1, PF_TYPE_GPU = 2, PF_TYPE_MULTIBAND = 3, PF_TYPE_RENDER = 4 };
+
+/* OpenCV / GImage type codes (GSLAM/GSLAM/core/GImage.h:27-36,97) */
+enum { PF_8UC1 = 0, PF_8UC3 = 16, PF_8UC4 = 24, PF_16SC3 = 19, PF_32FC1 = 5, PF_32FC3 = 21 };
+
+/* Image view, layout-compatible with cv::Mat / GSLAM::GImage headers
+ * (rows, cols, type, data; GImage.h:387-389).  step = bytes per row
+ * (0 = packed).  data may be a host pointer (pf_feed) or a device pointer
+ * (pf_feed_device). */
+typedef struct pf_image {
+    int         rows, cols, type;
+    const void* data;
+    size_t      step;
+} pf_image;
+
+/* The svar keys read on the path, as one struct. */
+typedef struct pf_options {
+    int    band_number;      /* MultiBandMap2DCPU.BandNumber   (5)  .cpp:260 */
+    int    force_float;      /* MultiBandMap2DCPU.ForceFloat   (0)  .cpp:444 */
+    int    high_quality_show;/* MultiBandMap2DCPU.HighQualityShow (1) .cpp:261 */
+    int    weight_type;      /* Map2D.WeightType               (0)  .cpp:407 */
+    int    bg_color;         /* Result.BackGroundColor         (0)  .cpp:840 */
+    double resolution;       /* Map2D.Resolution (0 = auto)         .cpp:228 */
+    double scale;            /* Map2D.Scale                    (1)  .cpp:235 */
+    int    device;           /* HIP device ordinal (-1 = current)            */
+    int    shard_rank;       /* tile sharding: this rank ...                 */
+    int    shard_count;      /* ... of shard_count (1 = own every tile)      */
+    int    shard_block;      /* spatial-hash cell edge in tiles (default 8)  */
+    int    max_queue;        /* feed queue cap, drop-oldest (20)    .cpp:302 */
+} pf_options;
+
+typedef struct pf_map pf_map;
+
+/* --- lifecycle --------------------------------------------------------- */
+void    pf_default_options(pf_options* o);
+/* key=value setter accepting the reference's svar key names
+ * ("MultiBandMap2DCPU.BandNumber", "Map2D.Scale", ...); 1 if the key is known */
+int     pf_options_set(pf_options* o, const char* key, const char* value);
+/* Map2D::create(type, thread), Map2DFusion/Map2D.cpp:51-66.  Types CPU/GPU/
+ * MULTIBAND all map onto the multi-band GPU engine; NONE/RENDER -> NULL.   */
+pf_map* pf_create(int type, int thread, const pf_options* opt);
+void    pf_destroy(pf_map* m);
+const char* pf_last_error(void);
+
+/* --- Map2D virtuals ---------------------------------------------------- */
+/* Map2D::prepare(plane, camera, frames), MultiBandMap2DCPU.cpp:266-286.
+ * cam = {w,h,fx,fy,cx,cy} (PinHoleParameters, Map2D.h:37-43).  imgs may be
+ * NULL (only the poses size the grid when thread=0; with thread=1 frames
+ * that carry an image are queued and rendered first, Map2D.cpp:42).        */
+int     pf_prepare(pf_map* m, const double plane[7], const double cam[6],
+                   int n, const pf_image* imgs, const double* poses7);
+/* Map2D::feed(img, pose), MultiBandMap2DCPU.cpp:288-309.  Host BGR8 frame;
+ * the pixels are copied (pinned staging + async H2D) before returning.    */
+int     pf_feed(pf_map* m, const pf_image* img, const double pose[7]);
+/* Same, frame already resident in HBM (img->data is a device pointer that
+ * must stay valid until pf_sync).  thread=0 maps only.                     */
+int     pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]);
+/* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
+unsigned pf_queue_size(pf_map* m);
+/* drain the feed queue and the device stream (no reference counterpart:
+ * the reference is synchronous on the CPU)                                 */
+int     pf_sync(pf_map* m);
+/* Map2D::save(filename), MultiBandMap2DCPU.cpp:779-847.  Writes PNG (.png),
+ * else binary PPM.                                                         */
+int     pf_save(pf_map* m, const char* filename);
+/* save() without the file: whole-mosaic collapse into caller memory.  Call
+ * with bgr=NULL to query rows/cols/origin tile.                            */
+int     pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);
+
+/* --- MultiBandMap2DCPU::Ele tile surface (MultiBandMap2DCPU.h:32-51) ---- */
+int     pf_num_levels(pf_map* m);                        /* bandNum+1          */
+int     pf_pyramid_type(pf_map* m);                      /* PF_16SC3 | PF_32FC3 */
+/* MultiBandMap2DCPUData geometry (.h:61-69): dims={w,h,off_x,off_y},
+ * geo={min.x,min.y,max.x,max.y,eleSize,lengthPixel}.  Tile coordinates in
+ * this API are stable: dense grid index + off (they survive spreadMap).    */
+int     pf_grid(pf_map* m, int dims[4], double geo[6]);
+int     pf_tile_count(pf_map* m);
+int     pf_tile_coords(pf_map* m, int* xy, int cap);
+/* Ele::pyr_laplace[level] / Ele::weights[level]: D2H copy of one level.    */
+int     pf_get_tile_level(pf_map* m, int ix, int iy, int level, void* lap, float* w);
+/* Ele::blend(neighbors), .cpp:77-146: raw result in the pyramid type.      */
+int     pf_blend_tile_raw(pf_map* m, int ix, int iy, void* out);
+/* Ele::updateTexture's pixels, .cpp:149-160: blend -> BGR8 256x256.        */
+int     pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr256);
+/* batch form of the draw() loop (.cpp:705-742): blend every tile whose
+ * Ischanged flag is set, clear the flags; xy/bgr sized by cap tiles.       */
+int     pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap);
+/* unused-by-the-reference helpers kept for API completeness (.cpp:57-75)   */
+int     pf_normalize_using_weight_map(const float* weight, float* src3, size_t npix);
+int     pf_mul_weight_map(const float* weight, float* src3, size_t npix);
+
+/* --- multi-GPU seam exchange (no reference counterpart) ------ */
+/* owner rank of a tile under the spatial hash */
+int     pf_tile_owner(const pf_options* o, int ix, int iy);
+/* Halo strips for Ele::blend across ranks.  A "strip set" of tile (ix,iy)
+ * seen from a neighbour at (dx,dy) is the bytes blend() would copy from it
+ * (.cpp:101-116), all levels concatenated.  pf_halo_bytes gives its size;
+ * pack writes it to a device buffer, blend_tile_halo consumes up to 8 such
+ * device buffers (NULL = neighbour absent) in place of local tiles.        */
+size_t  pf_halo_bytes(pf_map* m, int dx, int dy);
+int     pf_halo_pack(pf_map* m, int ix, int iy, int dx, int dy, void* dev_out);
+int     pf_blend_tile_halo(pf_map* m, int ix, int iy, const void* const dev_halo[9], uint8_t* bgr256, void* raw);
+/* whole tiles for save()'s gather: bytes of one tile's pyramid + weights   */
+size_t  pf_tile_bytes(pf_map* m);
+int     pf_tile_export(pf_map* m, int ix, int iy, void* dev_out);
+int     pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in);
+
+/* --- measurement -------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the map's own stream.  mode 0 = off,
+ * 1 = every kernel.  Read returns count kernels; name[i] static strings.   */
+int     pf_profile_enable(pf_map* m, int mode);
+int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
+                        double* alg_bytes);
+int     pf_profile_reset(pf_map* m);
+/* frames rendered / rejected since creation */
+int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIFUSION_H */

@@ -1,0 +1,271 @@
+"""pi-slam-fusion_amd -- ctypes host binding of libpifusion.so.
+
+Mirrors the reference's Map2D interface (Map2DFusion/Map2D.h:79-98:
+create / prepare / feed / save / queueSize) and the MultiBandMap2DCPU::Ele tile
+surface (MultiBandMap2DCPU.h:32-51).  The arithmetic lives in the HIP library;
+this module only marshals pointers.  There is no CPU fallback: creating a map
+without a HIP device (or without the built library) raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpifusion.so")
+ELE_PIXELS = 256
+
+# Map2D::Map2DType (Map2D.h:83)
+NoType, TypeCPU, TypeGPU, TypeMultiBandCPU, TypeRender = 0, 1, 2, 3, 4
+PF_8UC3, PF_16SC3, PF_32FC3 = 16, 19, 21
+
+
+class Options(C.Structure):
+    _fields_ = [("band_number", C.c_int), ("force_float", C.c_int), ("high_quality_show", C.c_int),
+                ("weight_type", C.c_int), ("bg_color", C.c_int), ("resolution", C.c_double),
+                ("scale", C.c_double), ("device", C.c_int), ("shard_rank", C.c_int),
+                ("shard_count", C.c_int), ("shard_block", C.c_int), ("max_queue", C.c_int)]
+
+
+class Image(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("type", C.c_int), ("data", C.c_void_p),
+                ("step", C.c_size_t)]
+
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libpifusion.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libpifusion.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.pf_default_options.argtypes = [C.POINTER(Options)]; L.pf_default_options.restype = None
+    L.pf_options_set.argtypes = [C.POINTER(Options), C.c_char_p, C.c_char_p]
+    L.pf_create.argtypes = [C.c_int, C.c_int, C.POINTER(Options)]; L.pf_create.restype = vp
+    L.pf_destroy.argtypes = [vp]; L.pf_destroy.restype = None
+    L.pf_last_error.restype = C.c_char_p
+    L.pf_prepare.argtypes = [vp, dp, dp, C.c_int, C.POINTER(Image), dp]
+    L.pf_feed.argtypes = [vp, C.POINTER(Image), dp]
+    L.pf_feed_device.argtypes = [vp, C.POINTER(Image), dp]
+    L.pf_queue_size.argtypes = [vp]; L.pf_queue_size.restype = C.c_uint
+    L.pf_sync.argtypes = [vp]
+    L.pf_save.argtypes = [vp, C.c_char_p]
+    L.pf_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
+    L.pf_num_levels.argtypes = [vp]
+    L.pf_pyramid_type.argtypes = [vp]
+    L.pf_grid.argtypes = [vp, ip, dp]
+    L.pf_tile_count.argtypes = [vp]
+    L.pf_tile_coords.argtypes = [vp, ip, C.c_int]
+    L.pf_get_tile_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.pf_blend_tile_raw.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pf_blend_tile.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pf_blend_changed.argtypes = [vp, ip, vp, C.c_int]
+    L.pf_normalize_using_weight_map.argtypes = [vp, vp, C.c_size_t]
+    L.pf_mul_weight_map.argtypes = [vp, vp, C.c_size_t]
+    L.pf_tile_owner.argtypes = [C.POINTER(Options), C.c_int, C.c_int]
+    L.pf_halo_bytes.argtypes = [vp, C.c_int, C.c_int]; L.pf_halo_bytes.restype = C.c_size_t
+    L.pf_halo_pack.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    L.pf_blend_tile_halo.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), vp, vp]
+    L.pf_tile_bytes.argtypes = [vp]; L.pf_tile_bytes.restype = C.c_size_t
+    L.pf_tile_export.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pf_tile_import.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pf_profile_enable.argtypes = [vp, C.c_int]
+    L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
+    L.pf_profile_reset.argtypes = [vp]
+    L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    _lib = L
+    return L
+
+
+def default_options(**kw):
+    o = Options()
+    lib().pf_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def tile_owner(opt, ix, iy):
+    return lib().pf_tile_owner(C.byref(opt), ix, iy)
+
+
+def _pose(p):
+    a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Map2D:
+    """Map2D::create(type, thread) -> object with prepare/feed/save/queueSize."""
+
+    def __init__(self, handle, opt):
+        self._h = handle
+        self.opt = opt
+
+    @staticmethod
+    def create(type=TypeMultiBandCPU, thread=False, options=None, **kw):
+        opt = options if options is not None else default_options(**kw)
+        h = lib().pf_create(type, 1 if thread else 0, C.byref(opt))
+        if not h:
+            if type in (NoType, TypeRender):
+                return None
+            raise RuntimeError("pf_create failed: %s" % lib().pf_last_error().decode())
+        return Map2D(h, opt)
+
+    def close(self):
+        if self._h:
+            lib().pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- Map2D virtuals
+    def prepare(self, plane, camera, poses, images=None):
+        """plane: 7 doubles; camera: [w h fx fy cx cy]; poses: n x 7 camera-to-world."""
+        pl, ppl = _pose(plane); cam, pc = _pose(camera)
+        ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 7)
+        imgs = None
+        keep = []
+        if images is not None:
+            imgs = (Image * len(images))()
+            for i, im in enumerate(images):
+                im = np.ascontiguousarray(im, dtype=np.uint8); keep.append(im)
+                imgs[i] = Image(im.shape[0], im.shape[1], PF_8UC3, im.ctypes.data, 0)
+        return bool(lib().pf_prepare(self._h, ppl, pc, ps.shape[0], imgs, ps.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def feed(self, img, pose):
+        """img: HxWx3 uint8 BGR numpy array (host), or None for a geometry-only frame."""
+        p, pp = _pose(pose)
+        if img is None:
+            return bool(lib().pf_feed(self._h, None, pp))
+        img = np.ascontiguousarray(img)
+        typ = PF_8UC3 if (img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3) else -1
+        im = Image(img.shape[0], img.shape[1], typ, img.ctypes.data, 0)
+        return bool(lib().pf_feed(self._h, C.byref(im), pp))
+
+    def feed_device(self, data_ptr, rows, cols, pose, step=0):
+        """Frame already resident in HBM (e.g. torch tensor .data_ptr())."""
+        p, pp = _pose(pose)
+        im = Image(rows, cols, PF_8UC3, data_ptr, step)
+        return bool(lib().pf_feed_device(self._h, C.byref(im), pp))
+
+    def queueSize(self):
+        return int(lib().pf_queue_size(self._h))
+
+    def sync(self):
+        return bool(lib().pf_sync(self._h))
+
+    def save(self, filename):
+        return bool(lib().pf_save(self._h, filename.encode()))
+
+    def save_to_memory(self):
+        r, c, x0, y0 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if not lib().pf_save_to_memory(self._h, None, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
+            return None
+        out = np.empty((r.value, c.value, 3), np.uint8)
+        if not lib().pf_save_to_memory(self._h, out.ctypes.data, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
+            return None
+        return out, (x0.value, y0.value)
+
+    # ---- Ele surface
+    @property
+    def num_levels(self):
+        return lib().pf_num_levels(self._h)
+
+    @property
+    def dtype(self):
+        return np.float32 if lib().pf_pyramid_type(self._h) == PF_32FC3 else np.int16
+
+    def grid(self):
+        dims = (C.c_int * 4)(); geo = (C.c_double * 6)()
+        if not lib().pf_grid(self._h, dims, geo):
+            return None
+        return list(dims), list(geo)
+
+    def tiles(self):
+        n = lib().pf_tile_count(self._h)
+        xy = (C.c_int * (2 * max(n, 1)))()
+        lib().pf_tile_coords(self._h, xy, n)
+        return [(xy[2 * i], xy[2 * i + 1]) for i in range(n)]
+
+    def tile_level(self, ix, iy, level):
+        s = ELE_PIXELS >> level
+        lap = np.empty((s, s, 3), self.dtype); w = np.empty((s, s), np.float32)
+        ok = lib().pf_get_tile_level(self._h, ix, iy, level, lap.ctypes.data, w.ctypes.data)
+        return (lap, w) if ok else None
+
+    def blend_tile_raw(self, ix, iy):
+        out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), self.dtype)
+        return out if lib().pf_blend_tile_raw(self._h, ix, iy, out.ctypes.data) else None
+
+    def blend_tile(self, ix, iy):
+        out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
+        return out if lib().pf_blend_tile(self._h, ix, iy, out.ctypes.data) else None
+
+    def blend_changed(self, cap=4096):
+        xy = (C.c_int * (2 * cap))()
+        out = np.empty((cap, ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
+        n = lib().pf_blend_changed(self._h, xy, out.ctypes.data, cap)
+        return [(xy[2 * i], xy[2 * i + 1]) for i in range(n)], out[:n]
+
+    # ---- multi-GPU seam exchange
+    def halo_bytes(self, dx, dy):
+        return int(lib().pf_halo_bytes(self._h, dx, dy))
+
+    def halo_pack(self, ix, iy, dx, dy, dev_ptr):
+        return bool(lib().pf_halo_pack(self._h, ix, iy, dx, dy, dev_ptr))
+
+    def blend_tile_halo(self, ix, iy, halo_ptrs, raw=False):
+        arr = (C.c_void_p * 9)(*[(p if p else None) for p in halo_ptrs])
+        if raw:
+            out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), self.dtype)
+            ok = lib().pf_blend_tile_halo(self._h, ix, iy, arr, None, out.ctypes.data)
+        else:
+            out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
+            ok = lib().pf_blend_tile_halo(self._h, ix, iy, arr, out.ctypes.data, None)
+        return out if ok else None
+
+    def tile_bytes(self):
+        return int(lib().pf_tile_bytes(self._h))
+
+    def tile_export(self, ix, iy, dev_ptr):
+        return bool(lib().pf_tile_export(self._h, ix, iy, dev_ptr))
+
+    def tile_import(self, ix, iy, dev_ptr):
+        return bool(lib().pf_tile_import(self._h, ix, iy, dev_ptr))
+
+    # ---- measurement
+    def profile_enable(self, mode=1):
+        lib().pf_profile_enable(self._h, mode)
+
+    def profile_reset(self):
+        lib().pf_profile_reset(self._h)
+
+    def profile_read(self):
+        cap = 32
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_longlong * cap)(); by = (C.c_double * cap)()
+        k = lib().pf_profile_read(self._h, cap, names, ms, n, by)
+        return {names[i].decode(): {"ms": ms[i], "launches": n[i], "alg_bytes": by[i]} for i in range(k)}
+
+    def stats(self):
+        a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
+        lib().pf_stats(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return {"rendered": a.value, "rejected": b.value, "dropped": c.value}

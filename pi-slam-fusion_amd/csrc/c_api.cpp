@@ -1,0 +1,108 @@
+// c_api.cpp -- extern "C" surface of libpifusion.so (include/pifusion.h).
+#include "fusion_map.hpp"
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+using pf::FusionMap;
+
+struct pf_map { FusionMap impl; pf_map(int t, bool th, const pf_options& o) : impl(t, th, o) {} };
+
+extern "C" {
+
+void pf_default_options(pf_options* o)
+{
+    o->band_number = 5; o->force_float = 0; o->high_quality_show = 1; o->weight_type = 0; o->bg_color = 0;
+    o->resolution = 0; o->scale = 1; o->device = -1; o->shard_rank = 0; o->shard_count = 1; o->shard_block = 8;
+    o->max_queue = 20;
+}
+
+int pf_options_set(pf_options* o, const char* key, const char* value)
+{
+    if (!o || !key || !value) return 0;
+    const double v = std::atof(value);
+    if (!std::strcmp(key, "MultiBandMap2DCPU.BandNumber")) o->band_number = (int)v;
+    else if (!std::strcmp(key, "MultiBandMap2DCPU.ForceFloat")) o->force_float = (int)v;
+    else if (!std::strcmp(key, "MultiBandMap2DCPU.HighQualityShow")) o->high_quality_show = (int)v;
+    else if (!std::strcmp(key, "Map2D.WeightType")) o->weight_type = (int)v;
+    else if (!std::strcmp(key, "Result.BackGroundColor")) o->bg_color = (int)v;
+    else if (!std::strcmp(key, "Map2D.Resolution")) o->resolution = v;
+    else if (!std::strcmp(key, "Map2D.Scale")) o->scale = v;
+    else if (!std::strcmp(key, "Device")) o->device = (int)v;
+    else if (!std::strcmp(key, "Shard.Rank")) o->shard_rank = (int)v;
+    else if (!std::strcmp(key, "Shard.Count")) o->shard_count = (int)v;
+    else if (!std::strcmp(key, "Shard.Block")) o->shard_block = (int)v;
+    else if (!std::strcmp(key, "Map2D.MaxQueue")) o->max_queue = (int)v;
+    else return 0;
+    return 1;
+}
+
+pf_map* pf_create(int type, int thread, const pf_options* opt)
+{
+    if (type == PF_TYPE_NONE || type == PF_TYPE_RENDER) return nullptr;     // Map2D.cpp:53,56
+    pf_options o;
+    if (opt) o = *opt; else pf_default_options(&o);
+    pf_map* m = new (std::nothrow) pf_map(type, thread != 0, o);
+    if (m && !m->impl.ok()) { delete m; return nullptr; }
+    return m;
+}
+
+void pf_destroy(pf_map* m) { delete m; }
+const char* pf_last_error(void) { return pf::last_error(); }
+
+int pf_prepare(pf_map* m, const double plane[7], const double cam[6], int n, const pf_image* imgs, const double* poses7)
+{ return m && m->impl.prepare(plane, cam, n, imgs, poses7); }
+
+int pf_feed(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, false); }
+int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, true); }
+unsigned pf_queue_size(pf_map* m) { return m ? m->impl.queue_size() : 0; }
+int pf_sync(pf_map* m) { return m && m->impl.sync(); }
+int pf_save(pf_map* m, const char* filename) { return m && filename && m->impl.save(filename); }
+int pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
+{ return m && rows && cols && tx0 && ty0 && m->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
+
+int pf_num_levels(pf_map* m) { return m ? m->impl.num_levels() : 0; }
+int pf_pyramid_type(pf_map* m) { return m ? m->impl.pyramid_type() : 0; }
+int pf_grid(pf_map* m, int dims[4], double geo[6]) { return m && m->impl.grid(dims, geo); }
+int pf_tile_count(pf_map* m) { return m ? m->impl.tile_count() : 0; }
+int pf_tile_coords(pf_map* m, int* xy, int cap) { return m ? m->impl.tile_coords(xy, cap) : 0; }
+int pf_get_tile_level(pf_map* m, int ix, int iy, int level, void* lap, float* w) { return m && m->impl.get_tile_level(ix, iy, level, lap, w); }
+int pf_blend_tile_raw(pf_map* m, int ix, int iy, void* out) { return m && out && m->impl.blend_tile(ix, iy, out, nullptr, nullptr); }
+int pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr) { return m && bgr && m->impl.blend_tile(ix, iy, nullptr, bgr, nullptr); }
+int pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap) { return (m && xy && bgr && cap > 0) ? m->impl.blend_changed(xy, bgr, cap) : 0; }
+
+// MultiBandMap2DCPUEle::normalizeUsingWeightMap / mulWeightMap (.cpp:57-75): no caller in
+// the reference; host loops kept for API completeness.
+int pf_normalize_using_weight_map(const float* weight, float* src3, size_t npix)
+{
+    if (!weight || !src3) return 0;
+    for (size_t i = 0; i < npix; i++) {
+        const float d = (float)(weight[i] + 1e-5);
+        const float inv = 1.f / d;          // Point3_ operator/ multiplies by the reciprocal (Point.h:213-216)
+        src3[3 * i] = inv * src3[3 * i]; src3[3 * i + 1] = inv * src3[3 * i + 1]; src3[3 * i + 2] = inv * src3[3 * i + 2];
+    }
+    return 1;
+}
+int pf_mul_weight_map(const float* weight, float* src3, size_t npix)
+{
+    if (!weight || !src3) return 0;
+    for (size_t i = 0; i < npix; i++) { const float w = weight[i]; src3[3 * i] = w * src3[3 * i]; src3[3 * i + 1] = w * src3[3 * i + 1]; src3[3 * i + 2] = w * src3[3 * i + 2]; }
+    return 1;
+}
+
+int pf_tile_owner(const pf_options* o, int ix, int iy) { return o ? pf::tile_owner(o->shard_count, o->shard_block, ix, iy) : 0; }
+size_t pf_halo_bytes(pf_map* m, int dx, int dy) { return m ? m->impl.halo_bytes_for(dx, dy) : 0; }
+int pf_halo_pack(pf_map* m, int ix, int iy, int dx, int dy, void* dev_out) { return m && dev_out && m->impl.halo_pack(ix, iy, dx, dy, dev_out); }
+int pf_blend_tile_halo(pf_map* m, int ix, int iy, const void* const dev_halo[9], uint8_t* bgr, void* raw)
+{ return m && (bgr || raw) && m->impl.blend_tile(ix, iy, raw, bgr, dev_halo); }
+size_t pf_tile_bytes(pf_map* m) { return m ? m->impl.tile_bytes() : 0; }
+int pf_tile_export(pf_map* m, int ix, int iy, void* dev_out) { return m && dev_out && m->impl.tile_export(ix, iy, dev_out); }
+int pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in) { return m && dev_in && m->impl.tile_import(ix, iy, dev_in); }
+
+int pf_profile_enable(pf_map* m, int mode) { if (!m) return 0; m->impl.profile_enable(mode); return 1; }
+int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes)
+{ return m ? m->impl.profile_read(cap, names, total_ms, launches, alg_bytes) : 0; }
+int pf_profile_reset(pf_map* m) { if (!m) return 0; m->impl.profile_reset(); return 1; }
+int pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped) { if (!m) return 0; m->impl.stats(rendered, rejected, dropped); return 1; }
+
+}  // extern "C"

@@ -1,0 +1,815 @@
+// fusion_map.cpp -- host engine: prepare / feed / renderFrame / blend / save on
+// the GPU, following the control flow of Map2DFusion/MultiBandMap2DCPU.cpp.
+#include "fusion_map.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace pf {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; std::fprintf(stderr, "pifusion: %s\n", msg.c_str()); }
+const char* last_error() { return g_err.c_str(); }
+
+#define HIP_OK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return false;                                                                  \
+        }                                                                                  \
+    } while (0)
+
+static inline int floordiv(int a, int b) { int q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) q--; return q; }
+
+int tile_owner(int shard_count, int shard_block, int ix, int iy)
+{
+    if (shard_count <= 1) return 0;
+    const int b = shard_block > 0 ? shard_block : 8;
+    const uint32_t cx = (uint32_t)floordiv(ix, b), cy = (uint32_t)floordiv(iy, b);
+    const uint32_t h = (cx * 73856093u) ^ (cy * 19349663u);
+    return (int)(h % (uint32_t)shard_count);
+}
+
+// ------------------------------------------------------------------ store
+Tile* TileStore::find(int ix, int iy)
+{
+    auto it = map_.find(key(ix, iy));
+    return it == map_.end() ? nullptr : &it->second;
+}
+
+Tile* TileStore::get_or_create(int ix, int iy)
+{
+    auto it = map_.find(key(ix, iy));
+    if (it != map_.end()) return &it->second;
+    if (chunks_.empty() || next_in_chunk_ == chunk_slots_) {
+        // slabs of ~256 MiB: few hipMallocs, tiles of one neighbourhood stay close in HBM
+        chunk_slots_ = std::max<size_t>(16, (256u << 20) / slot_bytes_);
+        void* p = nullptr;
+        if (hipMalloc(&p, chunk_slots_ * slot_bytes_) != hipSuccess) { set_error("tile store: hipMalloc failed"); return nullptr; }
+        chunks_.push_back((char*)p);
+        next_in_chunk_ = 0;
+    }
+    Tile t;
+    t.base = chunks_.back() + next_in_chunk_++ * slot_bytes_;
+    return &map_.emplace(key(ix, iy), t).first->second;
+}
+
+void TileStore::clear()
+{
+    for (char* c : chunks_) (void)hipFree(c);
+    chunks_.clear(); map_.clear(); next_in_chunk_ = chunk_slots_ = 0;
+}
+
+bool DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return true;
+    release();
+    const size_t want = bytes + bytes / 4;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; set_error("hipMalloc failed"); return false; }
+    cap = want;
+    return true;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+// ------------------------------------------------------------------ setup
+FusionMap::FusionMap(int /*type*/, bool thread, const pf_options& opt) : opt_(opt), thread_(thread)
+{
+    const int lim = (int)std::ceil(std::log((double)kElePixels) / std::log(2.0));      // .cpp:263
+    band_num_ = std::min(opt_.band_number, lim);
+    if (band_num_ < 0) band_num_ = 0;
+    lay_ = make_layout(band_num_, opt_.force_float != 0);
+    store_.configure(lay_.slot_bytes);
+    if (opt_.max_queue <= 0) opt_.max_queue = 20;
+    if (opt_.shard_count < 1) opt_.shard_count = 1;
+    if (opt_.shard_block < 1) opt_.shard_block = 8;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        set_error("no HIP device: the fusion path has no CPU fallback");
+        return;
+    }
+    if (opt_.device >= 0) device_ = opt_.device;
+    else if (hipGetDevice(&device_) != hipSuccess) device_ = 0;
+    if (device_ >= ndev) { set_error("device ordinal out of range"); return; }
+    if (hipSetDevice(device_) != hipSuccess) { set_error("hipSetDevice failed"); return; }
+    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return; }
+    for (int i = 0; i < kTableRing; i++)
+        if (hipEventCreateWithFlags(&table_ev_[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return; }
+    init_ok_ = true;
+    if (thread_) worker_ = std::thread([this] { worker(); });
+}
+
+FusionMap::~FusionMap()
+{
+    if (worker_.joinable()) {
+        { std::lock_guard<std::mutex> l(qmu_); stop_ = true; }
+        qcv_.notify_all();
+        worker_.join();
+    }
+    if (!init_ok_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    (void)hipStreamSynchronize(copy_stream_);
+    prof_harvest();
+    for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    for (auto& s : slots_) { if (s.dev) (void)hipFree(s.dev); if (s.consumed) (void)hipEventDestroy(s.consumed); }
+    for (int i = 0; i < kTableRing; i++) {
+        if (table_host_[i]) (void)hipHostFree(table_host_[i]);
+        table_dev_[i].release();
+        if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
+    }
+    for (int i = 0; i < kMaxLevels; i++) { g_[i].release(); wgt_[i].release(); blend_lv_[i].release(); }
+    blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release();
+    store_.clear();
+    (void)hipStreamDestroy(stream_);
+    (void)hipStreamDestroy(copy_stream_);
+}
+
+bool FusionMap::set_device() { HIP_OK(hipSetDevice(device_)); return true; }
+
+// ---------------------------------------------------------------- profile
+void FusionMap::profile_enable(int mode) { std::lock_guard<std::mutex> l(mu_); prof_mode_ = mode; }
+
+void FusionMap::prof_begin(int id, double bytes)
+{
+    if (!prof_mode_) return;
+    auto get = [&]() { hipEvent_t e; if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); } else (void)hipEventCreate(&e); return e; };
+    prof_cur_ = { id, get(), get(), bytes };
+    (void)hipEventRecord(prof_cur_.a, stream_);
+}
+
+void FusionMap::prof_end()
+{
+    if (!prof_mode_) return;
+    (void)hipEventRecord(prof_cur_.b, stream_);
+    prof_pending_.push_back(prof_cur_);
+    if (prof_pending_.size() > 4096) { (void)hipStreamSynchronize(stream_); prof_harvest(); }
+}
+
+void FusionMap::prof_harvest()
+{
+    for (auto& r : prof_pending_) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { prof_ms_[r.id] += ms; prof_n_[r.id]++; prof_bytes_[r.id] += r.bytes; }
+        ev_pool_.push_back(r.a); ev_pool_.push_back(r.b);
+    }
+    prof_pending_.clear();
+}
+
+int FusionMap::profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    prof_harvest();
+    int n = 0;
+    for (int i = 0; i < K_COUNT && n < cap; i++, n++) {
+        names[n] = kernel_name(i); ms[n] = prof_ms_[i]; launches[n] = prof_n_[i]; bytes[n] = prof_bytes_[i];
+    }
+    return n;
+}
+
+void FusionMap::profile_reset()
+{
+    std::lock_guard<std::mutex> l(mu_);
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    prof_harvest();
+    for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; }
+}
+
+void FusionMap::stats(long long* rendered, long long* rejected, long long* dropped)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (rendered) *rendered = n_rendered_;
+    if (rejected) *rejected = n_rejected_;
+    std::lock_guard<std::mutex> q(qmu_);
+    if (dropped) *dropped = n_dropped_;
+}
+
+// ---------------------------------------------------------------- prepare
+// Map2DPrepare::prepare (Map2D.cpp:32-49) + MultiBandMap2DCPUData::prepare
+// (.cpp:199-255) + MultiBandMap2DCPU::prepare (.cpp:266-286)
+bool FusionMap::prepare(const double plane7[7], const double cam[6], int n, const pf_image* imgs, const double* poses7)
+{
+    if (!init_ok_) { set_error("prepare: no device"); return false; }
+    if (n == 0 || !poses7 || cam[0] <= 0 || cam[1] <= 0 || cam[2] == 0 || cam[3] == 0) {
+        std::fprintf(stderr, "Map2D::prepare:Not valid prepare!\n");
+        return false;
+    }
+    Camera c{ cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], 1. / cam[2], 1. / cam[3] };
+    const Pose plane = pose_from7(plane7), pinv = inverse(plane);
+    double mx[3] = { -1e10, -1e10, -1e10 }, mn[3] = { 1e10, 1e10, 1e10 };
+    std::vector<Pose> local(n);
+    for (int i = 0; i < n; i++) {
+        local[i] = mul(pinv, pose_from7(poses7 + 7 * i));
+        for (int k = 0; k < 3; k++) {
+            mx[k] = local[i].t[k] > mx[k] ? local[i].t[k] : mx[k];
+            mn[k] = local[i].t[k] < mn[k] ? local[i].t[k] : mn[k];
+        }
+    }
+    if (mn[2] * mx[2] <= 0) return false;
+    const double maxh = mx[2] > 0 ? mx[2] : -mn[2];
+    const double lx = (c.w - c.cx) * c.fxinv - (0 - c.cx) * c.fxinv;
+    const double ly = (c.h - c.cy) * c.fyinv - (0 - c.cy) * c.fyinv;
+    const double radius = 0.5 * maxh * std::sqrt((lx * lx + ly * ly));
+    double length_pixel = opt_.resolution;
+    if (!length_pixel) {
+        length_pixel = 2 * radius / std::sqrt(c.w * c.w + c.h * c.h);
+        length_pixel /= opt_.scale;
+    }
+    std::printf("Map2D.Resolution=%g\n", length_pixel);
+    mn[0] = mn[0] - radius; mn[1] = mn[1] - radius;
+    mx[0] = mx[0] + radius; mx[1] = mx[1] + radius;
+    double ctr[3];
+    for (int k = 0; k < 3; k++) ctr[k] = 0.5 * (mn[k] + mx[k]);
+    for (int k = 0; k < 3; k++) { mn[k] = 2 * mn[k] - ctr[k]; mx[k] = 2 * mx[k] - ctr[k]; }
+    const double ele_size = kElePixels * length_pixel;
+    const int w = (int)std::ceil((mx[0] - mn[0]) / ele_size);
+    const int h = (int)std::ceil((mx[1] - mn[1]) / ele_size);
+    mx[0] = mn[0] + ele_size * w;
+    mx[1] = mn[1] + ele_size * h;
+
+    {
+        // drop frames queued against the old preparation (.cpp:362-376 bails on p!=prepared)
+        std::unique_lock<std::mutex> q(qmu_);
+        for (auto& f : queue_) if (f.slot >= 0) slots_[f.slot].queued = false;
+        queue_.clear();
+        idle_cv_.wait(q, [this] { return !worker_busy_; });
+    }
+    std::lock_guard<std::mutex> l(mu_);
+    if (!set_device()) return false;
+    HIP_OK(hipStreamSynchronize(stream_));
+    store_.clear();
+    plane_ = plane; plane_inv_ = pinv; cam_ = c;
+    length_pixel_ = length_pixel; length_pixel_inv_ = 1. / length_pixel;
+    ele_size_ = ele_size; ele_size_inv_ = 1. / ele_size;
+    std::memcpy(min_, mn, sizeof(mn)); std::memcpy(max_, mx, sizeof(mx));
+    w_ = w; h_ = h; off_x_ = off_y_ = 0;
+    valid_ = true;
+    if (thread_ && imgs) {
+        // with a render thread the prepare frames are rendered first (Map2D.cpp:42, .cpp:606-615)
+        for (int i = 0; i < n; i++) {
+            if (!imgs[i].data) continue;
+            const int slot = acquire_slot((size_t)imgs[i].rows * imgs[i].cols * 3);
+            if (slot < 0 || !upload(&imgs[i], slot)) return false;
+            std::lock_guard<std::mutex> q(qmu_);
+            slots_[slot].queued = true;
+            queue_.push_back({ slot, nullptr, (long)imgs[i].cols * 3, imgs[i].rows, imgs[i].cols, local[i] });
+        }
+        qcv_.notify_all();
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------- feed
+int FusionMap::acquire_slot(size_t bytes)
+{
+    // called with mu_ held.  A slot is reusable once it left the queue and the
+    // kernels that read it have completed.
+    const size_t limit = (size_t)opt_.max_queue + 4;
+    for (int pass = 0; pass < 2; pass++) {
+        int oldest_pending = -1;
+        for (size_t i = 0; i < slots_.size(); i++) {
+            FrameSlot& s = slots_[i];
+            { std::lock_guard<std::mutex> q(qmu_); if (s.queued) continue; }
+            if (s.pending) {
+                if (hipEventQuery(s.consumed) == hipSuccess) s.pending = false;
+                else { if (oldest_pending < 0) oldest_pending = (int)i; continue; }
+            }
+            if (s.cap < bytes) {
+                if (s.dev) (void)hipFree(s.dev);
+                s.dev = nullptr; s.cap = 0;
+                if (hipMalloc((void**)&s.dev, bytes + 64) != hipSuccess) { set_error("frame slot hipMalloc failed"); return -1; }
+                s.cap = bytes;
+            }
+            return (int)i;
+        }
+        if (slots_.size() < limit) {
+            FrameSlot s;
+            if (hipMalloc((void**)&s.dev, bytes + 64) != hipSuccess) { set_error("frame slot hipMalloc failed"); return -1; }
+            s.cap = bytes;
+            if (hipEventCreateWithFlags(&s.consumed, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
+            slots_.push_back(s);
+            return (int)slots_.size() - 1;
+        }
+        if (oldest_pending >= 0) { (void)hipEventSynchronize(slots_[oldest_pending].consumed); slots_[oldest_pending].pending = false; }
+    }
+    set_error("no free frame slot");
+    return -1;
+}
+
+bool FusionMap::upload(const pf_image* img, int slot)
+{
+    const size_t row = (size_t)img->cols * 3, step = img->step ? img->step : row;
+    HIP_OK(hipMemcpy2DAsync(slots_[slot].dev, row, img->data, step, row, img->rows, hipMemcpyHostToDevice, copy_stream_));
+    // the caller may release its pixels when feed() returns
+    HIP_OK(hipStreamSynchronize(copy_stream_));
+    return true;
+}
+
+// MultiBandMap2DCPU::feed (.cpp:288-309)
+bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr)
+{
+    if (!init_ok_) { set_error("feed: no device"); return false; }
+    QueuedFrame f{};
+    {
+        std::lock_guard<std::mutex> l(mu_);
+        if (!valid_) return false;
+        if (!set_device()) return false;
+        f.pose = mul(plane_inv_, pose_from7(pose7));
+        f.slot = -1; f.ext = nullptr;
+        if (img) {
+            // wrong size/type is reported by renderFrame (.cpp:319-323); keep that order of checks
+            f.rows = img->rows; f.cols = img->cols;
+            if (img->type != PF_8UC3 || img->cols != cam_.w || img->rows != cam_.h) {
+                std::fprintf(stderr, "MultiBandMap2DCPU::renderFrame: frame.first.cols!=p->_camera.w||frame.first.rows!=p->_camera.h||frame.first.type()!=CV_8UC3\n");
+                if (!thread_) { n_rejected_++; return false; }
+                return true;    // the threaded reference enqueues and fails later on the render thread
+            }
+            if (img->data) {
+                if (device_ptr) {
+                    if (thread_) { set_error("pf_feed_device needs a thread=0 map"); return false; }
+                    f.ext = (const uint8_t*)img->data; f.step = img->step ? (long)img->step : (long)img->cols * 3;
+                } else {
+                    f.slot = acquire_slot((size_t)img->rows * img->cols * 3);
+                    if (f.slot < 0 || !upload(img, f.slot)) return false;
+                    f.step = (long)img->cols * 3;
+                }
+            }
+        }
+    }
+    if (thread_) {
+        std::lock_guard<std::mutex> q(qmu_);
+        if (f.slot >= 0) slots_[f.slot].queued = true;
+        queue_.push_back(f);
+        if ((int)queue_.size() > opt_.max_queue) {          // .cpp:302 drop-oldest
+            if (queue_.front().slot >= 0) slots_[queue_.front().slot].queued = false;
+            queue_.pop_front();
+            n_dropped_++;
+        }
+        qcv_.notify_one();
+        return true;
+    }
+    std::lock_guard<std::mutex> l(mu_);
+    return render_frame(f);
+}
+
+unsigned FusionMap::queue_size() { std::lock_guard<std::mutex> q(qmu_); return (unsigned)queue_.size(); }
+
+// MultiBandMap2DCPU::run (.cpp:619-635) without the 10 ms sleep
+void FusionMap::worker()
+{
+    for (;;) {
+        QueuedFrame f;
+        {
+            std::unique_lock<std::mutex> q(qmu_);
+            qcv_.wait(q, [this] { return stop_ || !queue_.empty(); });
+            if (stop_) return;
+            f = queue_.front(); queue_.pop_front();
+            worker_busy_ = true;
+        }
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            if (valid_) render_frame(f);
+        }
+        {
+            std::lock_guard<std::mutex> q(qmu_);
+            if (f.slot >= 0) slots_[f.slot].queued = false;
+            worker_busy_ = false;
+        }
+        idle_cv_.notify_all();
+    }
+}
+
+bool FusionMap::sync()
+{
+    if (!init_ok_) return false;
+    if (thread_) {
+        std::unique_lock<std::mutex> q(qmu_);
+        idle_cv_.wait(q, [this] { return queue_.empty() && !worker_busy_; });
+    }
+    std::lock_guard<std::mutex> l(mu_);
+    if (!set_device()) return false;
+    HIP_OK(hipStreamSynchronize(stream_));
+    prof_harvest();
+    return true;
+}
+
+// spreadMap (.cpp:561-604): geometry only -- tiles live in a hash keyed by
+// stable coordinates, so nothing is re-laid out.
+bool FusionMap::spread_map(double xmin, double ymin, double xmax, double ymax)
+{
+    int xminInt = (int)std::floor((xmin - min_[0]) * ele_size_inv_);
+    int yminInt = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
+    int xmaxInt = (int)std::ceil((xmax - min_[0]) * ele_size_inv_);
+    int ymaxInt = (int)std::ceil((ymax - min_[1]) * ele_size_inv_);
+    xminInt = std::min(xminInt, 0); yminInt = std::min(yminInt, 0);
+    xmaxInt = std::max(xmaxInt, w_); ymaxInt = std::max(ymaxInt, h_);
+    const int w = xmaxInt - xminInt, h = ymaxInt - yminInt;
+    const double mnx = min_[0] + ele_size_ * xminInt, mny = min_[1] + ele_size_ * yminInt;
+    const double mxx = mnx + w * ele_size_, mxy = mny + h * ele_size_;
+    min_[0] = mnx; min_[1] = mny; max_[0] = mxx; max_[1] = mxy;
+    w_ = w; h_ = h; off_x_ += xminInt; off_y_ += yminInt;
+    return true;
+}
+
+// ------------------------------------------------------------ renderFrame
+bool FusionMap::render_frame(const QueuedFrame& f)
+{
+    // 1. pose -> ground points (.cpp:324-347)
+    double pts[8];
+    if (!footprint(cam_, f.pose, pts)) { n_rejected_++; return false; }
+    // 2. destination (.cpp:349-394)
+    double xmin = pts[0], xmax = xmin, ymin = pts[1], ymax = ymin;
+    for (int i = 1; i < 4; i++) {
+        if (pts[2 * i] < xmin) xmin = pts[2 * i];
+        if (pts[2 * i + 1] < ymin) ymin = pts[2 * i + 1];
+        if (pts[2 * i] > xmax) xmax = pts[2 * i];
+        if (pts[2 * i + 1] > ymax) ymax = pts[2 * i + 1];
+    }
+    if (xmin < min_[0] || xmax > max_[0] || ymin < min_[1] || ymax > max_[1])
+        if (!spread_map(xmin, ymin, xmax, ymax)) { n_rejected_++; return false; }
+    const int xminInt = (int)std::floor((xmin - min_[0]) * ele_size_inv_);
+    const int yminInt = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
+    const int xmaxInt = (int)std::ceil((xmax - min_[0]) * ele_size_inv_);
+    const int ymaxInt = (int)std::ceil((ymax - min_[1]) * ele_size_inv_);
+    if (xminInt < 0 || yminInt < 0 || xmaxInt > w_ || ymaxInt > h_ || xminInt >= xmaxInt || yminInt >= ymaxInt) {
+        std::fprintf(stderr, "MultiBandMap2DCPU::renderFrame:should never happen!\n");
+        n_rejected_++;
+        return false;
+    }
+    xmin = min_[0] + ele_size_ * xminInt;
+    ymin = min_[1] + ele_size_ * yminInt;
+    const uint8_t* src = f.ext ? f.ext : (f.slot >= 0 ? slots_[f.slot].dev : nullptr);
+    if (!src) return true;                      // geometry-only frame (other shards own its tiles)
+
+    // 3. homography (.cpp:427-441)
+    const float src4[8] = { 0.f, 0.f, (float)cam_.w, 0.f, 0.f, (float)cam_.h, (float)cam_.w, (float)cam_.h };
+    float dst4[8];
+    for (int i = 0; i < 4; i++) {
+        dst4[2 * i]     = (float)((pts[2 * i] - xmin) * length_pixel_inv_);
+        dst4[2 * i + 1] = (float)((pts[2 * i + 1] - ymin) * length_pixel_inv_);
+    }
+    double M0[9];
+    perspective_transform(src4, dst4, M0);
+
+    const int tx = xmaxInt - xminInt, ty = ymaxInt - yminInt, L = band_num_;
+    const int crows = ty * kElePixels, ccols = tx * kElePixels;
+
+    // tiles this shard owns inside the canvas
+    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0;
+    for (int y = 0; y < ty; y++)
+        for (int x = 0; x < tx; x++)
+            if (tile_owner(opt_.shard_count, opt_.shard_block, xminInt + x + off_x_, yminInt + y + off_y_) == opt_.shard_rank) {
+                bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
+            }
+    if (bx0 >= bx1) return true;                // nothing of this frame lands on this shard
+
+    // per-level windows: Gaussian level i must be valid on need[i] so that the
+    // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
+    struct Win { int x0, x1, y0, y1; } need[kMaxLevels];
+    auto clampw = [](int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); };
+    for (int i = L; i >= 0; i--) {
+        const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
+        int x0 = bx0 * ts, x1 = bx1 * ts, y0 = by0 * ts, y1 = by1 * ts;
+        if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
+        if (i < L) {
+            x0 = std::min(x0, 2 * need[i + 1].x0 - 2); x1 = std::max(x1, 2 * need[i + 1].x1 + 1);
+            y0 = std::min(y0, 2 * need[i + 1].y0 - 2); y1 = std::max(y1, 2 * need[i + 1].y1 + 1);
+        }
+        clampw(x0, x1, cols, need[i].x0, need[i].x1);
+        clampw(y0, y1, rows, need[i].y0, need[i].y1);
+    }
+    // level 0 is produced by the warp in 64x4 blocks
+    need[0].x0 = (need[0].x0 / 64) * 64; need[0].x1 = std::min(ccols, ((need[0].x1 + 63) / 64) * 64);
+    need[0].y0 = (need[0].y0 / 4) * 4;   need[0].y1 = std::min(crows, ((need[0].y1 + 3) / 4) * 4);
+
+    // workspace
+    const size_t es = lay_.f32 ? 4 : 2;
+    bool grow = false;
+    for (int i = 0; i <= L; i++) {
+        const size_t n = (size_t)(crows >> i) * (ccols >> i);
+        if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
+    }
+    if (table_cap_ < (size_t)tx * ty) grow = true;
+    if (grow) {
+        HIP_OK(hipStreamSynchronize(stream_));
+        for (int i = 0; i <= L; i++) {
+            const size_t n = (size_t)(crows >> i) * (ccols >> i);
+            if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
+        }
+        if (table_cap_ < (size_t)tx * ty) {
+            table_cap_ = (size_t)tx * ty * 2;
+            for (int i = 0; i < kTableRing; i++) {
+                if (table_host_[i]) (void)hipHostFree(table_host_[i]);
+                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, hipHostMallocDefault));
+                if (!table_dev_[i].reserve(table_cap_ * 8)) return false;
+                table_pending_[i] = false;
+            }
+        }
+    }
+
+    // tile table (Apply's tile loop, .cpp:478-492): slot address | fresh bit
+    const int ring = (int)(frame_seq_++ % kTableRing);
+    if (table_pending_[ring]) { HIP_OK(hipEventSynchronize(table_ev_[ring])); table_pending_[ring] = false; }
+    uint64_t* tab = table_host_[ring];
+    std::vector<Tile*> touched;
+    for (int y = 0; y < ty; y++)
+        for (int x = 0; x < tx; x++) {
+            const int sx = xminInt + x + off_x_, sy = yminInt + y + off_y_;
+            uint64_t ent = 0;
+            if (tile_owner(opt_.shard_count, opt_.shard_block, sx, sy) == opt_.shard_rank) {
+                Tile* t = store_.get_or_create(sx, sy);
+                if (!t) return false;
+                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
+                touched.push_back(t);
+            }
+            tab[y * tx + x] = ent;
+        }
+    HIP_OK(hipMemcpyAsync(table_dev_[ring].p, tab, (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
+    HIP_OK(hipEventRecord(table_ev_[ring], stream_));
+    table_pending_[ring] = true;
+    const uint64_t* dtab = (const uint64_t*)table_dev_[ring].p;
+
+    // warp (.cpp:443-452)
+    WarpArgs a{};
+    if (!invert3x3(M0, a.M)) std::memset(a.M, 0, sizeof(a.M));
+    a.srows = f.rows; a.scols = f.cols; a.sstep = f.step;
+    a.crows = crows; a.ccols = ccols;
+    a.y_off = need[0].y0; a.x_off = need[0].x0; a.wrows = need[0].y1 - need[0].y0; a.wcols = need[0].x1 - need[0].x0;
+    a.xc = (float)(f.cols / 2); a.yc = (float)(f.rows / 2);
+    a.dis_max = std::sqrt(a.xc * a.xc + a.yc * a.yc);
+    a.weight_type = opt_.weight_type;
+    const double win0 = (double)a.wrows * a.wcols;
+    prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
+    launch_warp(stream_, lay_.f32, src, a, g_[0].p, (float*)wgt_[0].p);
+    prof_end();
+
+    // Gaussian pyramids (.cpp:469 first loop, .cpp:471-474)
+    for (int i = 0; i < L; i++) {
+        const Win& d = need[i + 1];
+        const double nd = (double)(d.x1 - d.x0) * (d.y1 - d.y0);
+        prof_begin(K_PYRDOWN_IMG, nd * 4 * 3 * es + nd * 3 * es);
+        launch_pyrdown(stream_, lay_.f32 ? 1 : 0, g_[i].p, crows >> i, ccols >> i, g_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
+        prof_end();
+        prof_begin(K_PYRDOWN_W, nd * 4 * 4 + nd * 4);
+        launch_pyrdown(stream_, 2, wgt_[i].p, crows >> i, ccols >> i, wgt_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
+        prof_end();
+    }
+    // Laplacian + select into tiles (.cpp:469 second loop, .cpp:476-555)
+    for (int i = 0; i <= L; i++) {
+        const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
+        prof_begin(K_LAP_SELECT, n * (3 * es + 4 + 4) + (i < L ? n / 4 * 3 * es : 0));
+        launch_lap_select(stream_, lay_, i, g_[i].p, i < L ? g_[i + 1].p : nullptr, (const float*)wgt_[i].p,
+                          crows >> i, ccols >> i, dtab, tx, by0, by1, bx0, bx1);
+        prof_end();
+    }
+    HIP_OK(hipGetLastError());
+    if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
+    for (Tile* t : touched) { t->fresh = false; t->changed = true; }
+    n_rendered_++;
+    return true;
+}
+
+// ------------------------------------------------------------ tile access
+bool FusionMap::grid(int dims[4], double geo[6])
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!valid_) return false;
+    dims[0] = w_; dims[1] = h_; dims[2] = off_x_; dims[3] = off_y_;
+    geo[0] = min_[0]; geo[1] = min_[1]; geo[2] = max_[0]; geo[3] = max_[1]; geo[4] = ele_size_; geo[5] = length_pixel_;
+    return true;
+}
+
+int FusionMap::tile_count()
+{
+    std::lock_guard<std::mutex> l(mu_);
+    int n = 0;
+    store_.for_each([&](int, int, Tile& t) { if (!t.fresh) n++; });
+    return n;
+}
+
+int FusionMap::tile_coords(int* xy, int cap)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    std::vector<std::pair<int, int>> v;
+    store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) v.push_back({ iy, ix }); });
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) { xy[2 * i] = v[i].second; xy[2 * i + 1] = v[i].first; }
+    return (int)v.size();
+}
+
+bool FusionMap::get_tile_level(int ix, int iy, int level, void* lap, float* w)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh || level < 0 || level > band_num_) return false;
+    HIP_OK(hipStreamSynchronize(stream_));
+    const size_t n = (size_t)(kElePixels >> level) * (kElePixels >> level);
+    if (lap) HIP_OK(hipMemcpy(lap, t->base + lay_.lap_off[level], n * 3 * (lay_.f32 ? 4 : 2), hipMemcpyDeviceToHost));
+    if (w) HIP_OK(hipMemcpy(w, t->base + lay_.w_off[level], n * 4, hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool FusionMap::halo_pack(int ix, int iy, int dx, int dy, void* dev_out)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh) return false;
+    launch_halo_pack(stream_, lay_, t->base, dx, dy, dev_out);
+    HIP_OK(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool FusionMap::tile_export(int ix, int iy, void* dev_out)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh) return false;
+    HIP_OK(hipMemcpyAsync(dev_out, t->base, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    return true;
+}
+
+bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !valid_ || !set_device()) return false;
+    Tile* t = store_.get_or_create(ix, iy);
+    if (!t) return false;
+    HIP_OK(hipMemcpyAsync(t->base, dev_in, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    t->fresh = false; t->changed = true;
+    return true;
+}
+
+// ------------------------------------------------------------------ blend
+// Ele::blend (.cpp:77-146) for a batch of tiles.  halo (9 device pointers or
+// nullptr) substitutes packed strip sets for neighbours held by other shards;
+// it applies to single-tile calls only.
+bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const void* const* halo, void* raw_host, uint8_t* bgr_host)
+{
+    const int nl = band_num_ + 1, L = band_num_;
+    const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
+    const size_t tile_px = (size_t)kElePixels * kElePixels;
+    // group tiles by mode: full 3x3 available (border = 1<<(nl-1-i)) or self (border 0)
+    for (int mode = 0; mode < 2; mode++) {
+        std::vector<BlendSrc> srcs;
+        std::vector<int> idx;
+        for (size_t t = 0; t < tiles.size(); t++) {
+            Tile* self = store_.find(tiles[t].first, tiles[t].second);
+            if (!self || self->fresh) continue;
+            BlendSrc nb[9]; bool all = opt_.high_quality_show != 0;
+            for (int dy = -1; dy <= 1 && all; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int j = 3 * (dy + 1) + dx + 1;
+                    Tile* n = store_.find(tiles[t].first + dx, tiles[t].second + dy);
+                    if (n && !n->fresh) nb[j] = { n->base, 0 };
+                    else if (halo && halo[j]) nb[j] = { halo[j], 1 };
+                    else { all = false; break; }
+                }
+            if ((all ? 0 : 1) != mode) continue;
+            if (!all) { for (auto& b : nb) b = { nullptr, 0 }; nb[4] = { self->base, 0 }; }
+            srcs.insert(srcs.end(), nb, nb + 9);
+            idx.push_back((int)t);
+        }
+        const int batch = (int)idx.size();
+        if (!batch) continue;
+        const int b0 = mode == 0 ? (1 << (nl - 1)) : 0;
+        if (!blend_src_.reserve(srcs.size() * sizeof(BlendSrc))) return false;
+        HIP_OK(hipMemcpyAsync(blend_src_.p, srcs.data(), srcs.size() * sizeof(BlendSrc), hipMemcpyHostToDevice, stream_));
+        size_t stride[kMaxLevels];
+        for (int i = 0; i < nl; i++) {
+            const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
+            stride[i] = (((size_t)side * side * px + 255) / 256) * 256;
+            if (!blend_lv_[i].reserve(stride[i] * batch)) return false;
+        }
+        if (raw_host && !blend_out_raw_.reserve(tile_px * px * batch)) return false;
+        if (bgr_host && !blend_out_bgr_.reserve(tile_px * 3 * batch)) return false;
+        const BlendSrc* dsrc = (const BlendSrc*)blend_src_.p;
+        for (int i = 0; i < nl; i++) {
+            const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
+            prof_begin(K_BLEND_GATHER, (double)side * side * px * 2 * batch);
+            launch_blend_gather(stream_, lay_, i, b, dsrc, blend_lv_[i].p, stride[i], batch);
+            prof_end();
+        }
+        for (int i = L; i > 0; i--) {
+            const int b = mode == 0 ? (1 << (nl - i)) : 0, side = (kElePixels >> (i - 1)) + 2 * b;
+            prof_begin(K_COLLAPSE, (double)side * side * px * 2.25 * batch);
+            launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, stride[i - 1], blend_lv_[i].p, stride[i], side, side, batch);
+            prof_end();
+        }
+        prof_begin(K_BLEND_FINISH, (double)tile_px * (px + 4 + 3) * batch);
+        launch_blend_finish(stream_, lay_, blend_lv_[0].p, stride[0], b0, dsrc, raw_host ? blend_out_raw_.p : nullptr,
+                            bgr_host ? (uint8_t*)blend_out_bgr_.p : nullptr, batch);
+        prof_end();
+        HIP_OK(hipStreamSynchronize(stream_));
+        for (int k = 0; k < batch; k++) {
+            if (raw_host) HIP_OK(hipMemcpy((char*)raw_host + (size_t)idx[k] * tile_px * px, (char*)blend_out_raw_.p + (size_t)k * tile_px * px, tile_px * px, hipMemcpyDeviceToHost));
+            if (bgr_host) HIP_OK(hipMemcpy(bgr_host + (size_t)idx[k] * tile_px * 3, (char*)blend_out_bgr_.p + (size_t)k * tile_px * 3, tile_px * 3, hipMemcpyDeviceToHost));
+        }
+    }
+    return true;
+}
+
+bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh) return false;
+    std::vector<std::pair<int, int>> one{ { ix, iy } };
+    return blend_batch(one, halo, raw, bgr);
+}
+
+// the draw() loop's texture refresh (.cpp:705-742) without GL
+int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return 0;
+    std::vector<std::pair<int, int>> v;
+    store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh && t.changed) v.push_back({ iy, ix }); });
+    std::sort(v.begin(), v.end());
+    if ((int)v.size() > cap) v.resize(cap);
+    std::vector<std::pair<int, int>> tiles;
+    for (auto& p : v) tiles.push_back({ p.second, p.first });
+    if (tiles.empty()) return 0;
+    // bound the scratch: 64 tiles per batch
+    const size_t tile_px = (size_t)kElePixels * kElePixels * 3;
+    for (size_t o = 0; o < tiles.size(); o += 64) {
+        std::vector<std::pair<int, int>> part(tiles.begin() + o, tiles.begin() + std::min(tiles.size(), o + 64));
+        if (!blend_batch(part, nullptr, nullptr, bgr + o * tile_px)) return 0;
+    }
+    for (size_t i = 0; i < tiles.size(); i++) {
+        xy[2 * i] = tiles[i].first; xy[2 * i + 1] = tiles[i].second;
+        store_.find(tiles[i].first, tiles[i].second)->changed = false;
+    }
+    return (int)tiles.size();
+}
+
+// ------------------------------------------------------------------- save
+// MultiBandMap2DCPU::save (.cpp:779-847): paste all tiles per level, collapse
+// the whole mosaic once, 8U, background where level-0 weight is 0.
+bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !valid_ || !set_device()) return false;
+    if (w_ == 0 || h_ == 0) return false;
+    int mnx = 1000000, mny = 1000000, mxx = -1000000, mxy = -1000000, cnt = 0;
+    store_.for_each([&](int ix, int iy, Tile& t) {
+        if (t.fresh) return;
+        cnt++; mnx = std::min(mnx, ix); mny = std::min(mny, iy); mxx = std::max(mxx, ix); mxy = std::max(mxy, iy);
+    });
+    if (!cnt) return false;
+    const int wx = mxx + 1 - mnx, wy = mxy + 1 - mny;
+    *rows = wy * kElePixels; *cols = wx * kElePixels; *tx0 = mnx; *ty0 = mny;
+    if (!bgr) return true;
+    const int L = band_num_;
+    const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
+    std::vector<uint64_t> tab((size_t)wx * wy, 0);
+    store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) tab[(size_t)(iy - mny) * wx + (ix - mnx)] = (uint64_t)(uintptr_t)t.base; });
+    HIP_OK(hipStreamSynchronize(stream_));
+    if (!mosaic_table_.reserve(tab.size() * 8)) return false;
+    HIP_OK(hipMemcpy(mosaic_table_.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    for (int i = 0; i <= L; i++) {
+        const size_t n = (size_t)(*rows >> i) * (*cols >> i);
+        if (!blend_lv_[i].reserve(n * px)) return false;
+        prof_begin(K_MOSAIC_GATHER, (double)n * px * 2);
+        launch_mosaic_gather(stream_, lay_, i, (const uint64_t*)mosaic_table_.p, wx, wy, blend_lv_[i].p);
+        prof_end();
+    }
+    for (int i = L; i > 0; i--) {
+        prof_begin(K_COLLAPSE, (double)(*rows >> (i - 1)) * (*cols >> (i - 1)) * px * 2.25);
+        launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, 0, blend_lv_[i].p, 0, *rows >> (i - 1), *cols >> (i - 1), 1);
+        prof_end();
+    }
+    const size_t out_bytes = (size_t)*rows * *cols * 3;
+    if (!blend_out_bgr_.reserve(out_bytes)) return false;
+    prof_begin(K_SAVE_FINISH, (double)*rows * *cols * (px + 4 + 3));
+    launch_save_finish(stream_, lay_, blend_lv_[0].p, (const uint64_t*)mosaic_table_.p, wx, wy, opt_.bg_color, (uint8_t*)blend_out_bgr_.p);
+    prof_end();
+    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(hipMemcpy(bgr, blend_out_bgr_.p, out_bytes, hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool FusionMap::save(const char* filename)
+{
+    int rows, cols, tx0, ty0;
+    if (!save_to_memory(nullptr, &rows, &cols, &tx0, &ty0)) return false;
+    std::vector<uint8_t> img((size_t)rows * cols * 3);
+    if (!save_to_memory(img.data(), &rows, &cols, &tx0, &ty0)) return false;
+    if (!write_image_file(filename, img.data(), rows, cols)) return false;
+    std::printf("Resolution:[%d %d]\n", cols, rows);
+    return true;
+}
+
+}  // namespace pf

@@ -1,0 +1,167 @@
+// fusion_map.hpp -- host engine behind the Map2D boundary: the GPU counterpart of
+// MultiBandMap2DCPU (Map2DFusion/MultiBandMap2DCPU.h:28-132).
+#pragma once
+#include "../../include/pifusion.h"
+#include "geometry.hpp"
+#include "kernels.hpp"
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace pf {
+
+void set_error(const std::string& msg);
+const char* last_error();
+
+// spatial-hash owner of a tile; cells of shard_block tiles
+int tile_owner(int shard_count, int shard_block, int ix, int iy);
+
+// ---- tile store: spatial hash (ix,iy) -> slot in an HBM slab pool ----------
+// replaces the dense vector<SPtr<Ele>> + spreadMap re-layout (.h:91, .cpp:561-604)
+struct Tile {
+    char* base = nullptr;   // slot base in HBM
+    bool  fresh = true;     // pyr_laplace[i].empty() (.cpp:498): first write copies unconditionally
+    bool  changed = false;  // Ele::Ischanged
+};
+
+class TileStore {
+public:
+    ~TileStore() { clear(); }
+    void  configure(size_t slot_bytes) { slot_bytes_ = slot_bytes; }
+    Tile* find(int ix, int iy);
+    Tile* get_or_create(int ix, int iy);          // nullptr on HBM exhaustion
+    void  clear();
+    size_t size() const { return map_.size(); }
+    template <class F> void for_each(F f) { for (auto& kv : map_) f((int)(int32_t)(kv.first >> 32), (int)(int32_t)(kv.first & 0xffffffffu), kv.second); }
+private:
+    static uint64_t key(int ix, int iy) { return ((uint64_t)(uint32_t)ix << 32) | (uint32_t)iy; }
+    std::unordered_map<uint64_t, Tile> map_;
+    std::vector<char*> chunks_;
+    size_t slot_bytes_ = 0, chunk_slots_ = 0, next_in_chunk_ = 0;
+};
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    bool   reserve(size_t bytes);     // grow-only; caller must have synchronised users
+    void   release();
+};
+
+struct FrameSlot {
+    uint8_t*   dev = nullptr;
+    size_t     cap = 0;
+    hipEvent_t consumed = nullptr;    // recorded on the compute stream after the last kernel reading it
+    bool       pending = false;       // consumed has been recorded and not yet observed complete
+    bool       queued = false;        // sits in the feed queue
+};
+
+struct QueuedFrame {
+    int    slot;            // index into frame slots, -1 = geometry only
+    const uint8_t* ext;     // externally owned device pointer (pf_feed_device) or nullptr
+    long   step;
+    int    rows, cols;
+    Pose   pose;            // plane coordinates
+};
+
+class FusionMap {
+public:
+    FusionMap(int type, bool thread, const pf_options& opt);
+    ~FusionMap();
+    bool ok() const { return init_ok_; }
+
+    bool prepare(const double plane[7], const double cam[6], int n, const pf_image* imgs, const double* poses7);
+    bool feed(const pf_image* img, const double pose[7], bool device_ptr);
+    unsigned queue_size();
+    bool sync();
+    bool save(const char* filename);
+    bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
+
+    int  num_levels() const { return band_num_ + 1; }
+    int  pyramid_type() const { return lay_.f32 ? PF_32FC3 : PF_16SC3; }
+    bool grid(int dims[4], double geo[6]);
+    int  tile_count();
+    int  tile_coords(int* xy, int cap);
+    bool get_tile_level(int ix, int iy, int level, void* lap, float* w);
+    bool blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo);
+    int  blend_changed(int* xy, uint8_t* bgr, int cap);
+    size_t halo_bytes_for(int dx, int dy) const { return halo_bytes(lay_, dx, dy); }
+    bool halo_pack(int ix, int iy, int dx, int dy, void* dev_out);
+    size_t tile_bytes() const { return lay_.slot_bytes; }
+    bool tile_export(int ix, int iy, void* dev_out);
+    bool tile_import(int ix, int iy, const void* dev_in);
+
+    void profile_enable(int mode);
+    int  profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes);
+    void profile_reset();
+    void stats(long long* rendered, long long* rejected, long long* dropped);
+    const pf_options& options() const { return opt_; }
+
+private:
+    bool render_frame(const QueuedFrame& f);                       // .cpp:311-558
+    bool spread_map(double xmin, double ymin, double xmax, double ymax);   // .cpp:561-604
+    void worker();                                                 // .cpp:619-635
+    int  acquire_slot(size_t bytes);
+    bool upload(const pf_image* img, int slot);
+    bool blend_batch(const std::vector<std::pair<int,int>>& tiles, const void* const* halo, void* raw_host, uint8_t* bgr_host);
+    void prof_begin(int id, double bytes);
+    void prof_end();
+    void prof_harvest();
+    bool set_device();
+
+    pf_options opt_;
+    int        band_num_ = 5;
+    TileLayout lay_{};
+    bool       thread_ = false, init_ok_ = false;
+    int        device_ = 0;
+    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+
+    // prepared state, guarded by mu_
+    std::mutex mu_;
+    bool   valid_ = false;
+    Pose   plane_{}, plane_inv_{};
+    Camera cam_{};
+    double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
+    double min_[3]{}, max_[3]{};
+    int    w_ = 0, h_ = 0, off_x_ = 0, off_y_ = 0;
+    TileStore store_;
+
+    // per-frame workspace (grow-only)
+    DevBuf g_[kMaxLevels], wgt_[kMaxLevels];
+    static constexpr int kTableRing = 8;
+    uint64_t*  table_host_[kTableRing]{};
+    DevBuf     table_dev_[kTableRing];
+    size_t     table_cap_ = 0;
+    hipEvent_t table_ev_[kTableRing]{};
+    bool       table_pending_[kTableRing]{};
+    unsigned long long frame_seq_ = 0;
+
+    // blend / save scratch
+    DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_;
+
+    // frame staging + feed queue
+    std::vector<FrameSlot> slots_;
+    std::mutex qmu_;
+    std::condition_variable qcv_, idle_cv_;
+    std::deque<QueuedFrame> queue_;
+    bool worker_busy_ = false, stop_ = false;
+    std::thread worker_;
+
+    // profile
+    struct ProfRec { int id; hipEvent_t a, b; double bytes; };
+    int prof_mode_ = 0;
+    std::vector<ProfRec> prof_pending_;
+    std::vector<hipEvent_t> ev_pool_;
+    double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};
+    ProfRec prof_cur_{};
+    long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0;
+};
+
+// PNG (zlib) / PPM writer for save()
+bool write_image_file(const char* filename, const uint8_t* bgr, int rows, int cols);
+
+}  // namespace pf

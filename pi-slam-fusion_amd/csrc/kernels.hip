@@ -1,0 +1,504 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the multi-band
+// fusion hot path.  Compiled with -ffp-contract=off: every fp32/fp64 operation
+// below is evaluated in exactly the written order so that results are
+// bit-identical to the reference's OpenCV 2.4.9 arithmetic.
+//
+// Path (reference: Map2DFusion/MultiBandMap2DCPU.cpp):
+//   k_warp        :443-452  convertTo + warpPerspective(LINEAR,REFLECT) of the
+//                           frame + warpPerspective(NEAREST,CONSTANT) of the
+//                           radial weight map (:396-418, recomputed per pixel)
+//   k_pyrdown     :469,:474 cv::pyrDown chain (image and weight)
+//   k_lap_select  :469 + :476-555  pyrUp+subtract of createLaplacePyr fused
+//                           with the per-tile max-weight select
+//   k_blend_* / k_collapse  :77-146 Ele::blend, :836 save's collapse
+//   k_mosaic_gather / k_save_finish  :806-840 save
+#include "kernels.hpp"
+#include <climits>
+
+namespace pf {
+
+// ---------------------------------------------------------------- helpers
+__device__ __forceinline__ int border_reflect(int p, int len)          // BORDER_REFLECT  fedcba|abcdefgh|hgfedcb
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    const int m = 2 * len;
+    int q = p % m;
+    if (q < 0) q += m;
+    return q < len ? q : m - 1 - q;
+}
+__device__ __forceinline__ int border_reflect101(int p, int len)       // BORDER_REFLECT_101 gfedcb|abcdefgh|gfedcba
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    const int m = 2 * len - 2;
+    int q = p % m;
+    if (q < 0) q += m;
+    return q < len ? q : m - q;
+}
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ double clamp_int_range(double v)
+{
+    v = (v < (double)INT_MAX) ? v : (double)INT_MAX;     // std::min((double)INT_MAX, v)
+    v = ((double)INT_MIN < v) ? v : (double)INT_MIN;     // std::max((double)INT_MIN, v)
+    return v;
+}
+
+template <bool F32> struct Pix;
+template <> struct Pix<false> { using T = short; using WT = int;   static constexpr int bytes = 2; };
+template <> struct Pix<true>  { using T = float; using WT = float; static constexpr int bytes = 4; };
+
+__device__ __forceinline__ short cast_down(int v)   { return (short)((v + 128) >> 8); }
+__device__ __forceinline__ float cast_down(float v) { return v * (1.f / 256); }
+__device__ __forceinline__ short cast_up(int v)     { return (short)((v + 32) >> 6); }
+__device__ __forceinline__ float cast_up(float v)   { return v * (1.f / 64); }
+__device__ __forceinline__ short sat_sub(short a, short b) { return (short)sat_short((int)a - (int)b); }
+__device__ __forceinline__ float sat_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ short sat_add(short a, short b) { return (short)sat_short((int)a + (int)b); }
+__device__ __forceinline__ float sat_add(float a, float b) { return a + b; }
+
+// ------------------------------------------------------------------- warp
+// One wave = one 64-pixel OpenCV coordinate block row (bw0 = 64): the block
+// origin terms X0/Y0/W0 are wave-uniform, lane = x1.  4 waves = 4 rows.
+template <bool F32>
+__global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, WarpArgs a,
+                                               void* __restrict__ g0v, float* __restrict__ w0)
+{
+    using T = typename Pix<F32>::T;
+    __shared__ T stage[4][192];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xb = a.x_off + blockIdx.x * 64;
+    const int y  = a.y_off + blockIdx.y * 4 + wave;
+    const int x1 = lane;
+
+    const double X0 = a.M[0] * xb + a.M[1] * y + a.M[2];
+    const double Y0 = a.M[3] * xb + a.M[4] * y + a.M[5];
+    const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
+    const double W  = W0 + a.M[6] * x1;
+    const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
+
+    // --- weight: INTER_NEAREST, BORDER_CONSTANT(0), analytic radial weight
+    float wv = 0.f;
+    {
+        const double Wn = W ? 1. / W : 0;
+        const int X = __double2int_rn(clamp_int_range(xn * Wn));
+        const int Y = __double2int_rn(clamp_int_range(yn * Wn));
+        const int sx = sat_short(X), sy = sat_short(Y);
+        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
+            const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
+            float dis = dy * dy + dx * dx;
+            dis = 1.f - sqrtf(dis) / a.dis_max;
+            wv = a.weight_type == 0 ? dis : dis * dis;
+            if ((double)wv <= 1e-5) wv = 1e-5f;
+        }
+    }
+    // --- image: INTER_LINEAR (1/32 px), BORDER_REFLECT
+    T out[3];
+    {
+        const double Wl = W ? 32. / W : 0;
+        const int X = __double2int_rn(clamp_int_range(xn * Wl));
+        const int Y = __double2int_rn(clamp_int_range(yn * Wl));
+        const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+        const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+        const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
+        int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
+        if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
+            sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
+            sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
+        }
+        const uint8_t* r0 = src + (long)sy0 * a.sstep;
+        const uint8_t* r1 = src + (long)sy1 * a.sstep;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float v0 = (float)r0[sx0 * 3 + k], v1 = (float)r0[sx1 * 3 + k];
+            float v2 = (float)r1[sx0 * 3 + k], v3 = (float)r1[sx1 * 3 + k];
+            if (F32) {
+                const float s = (float)(1. / 255.);
+                v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
+            }
+            const float t = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+            if constexpr (F32) out[k] = t;
+            else out[k] = (short)sat_short(__float2int_rn(t));
+        }
+    }
+    // --- stores: weight is lane-contiguous; pixels go through LDS so that the
+    //     wave writes whole dwords
+    const long pix = (long)y * a.ccols + xb;
+    w0[pix + lane] = wv;
+    stage[wave][lane * 3 + 0] = out[0];
+    stage[wave][lane * 3 + 1] = out[1];
+    stage[wave][lane * 3 + 2] = out[2];
+    __syncthreads();
+    const uint32_t* st = reinterpret_cast<const uint32_t*>(stage[wave]);
+    uint32_t* g = reinterpret_cast<uint32_t*>(reinterpret_cast<T*>(g0v) + pix * 3);
+    if constexpr (F32) {
+        g[lane] = st[lane]; g[64 + lane] = st[64 + lane]; g[128 + lane] = st[128 + lane];
+    } else {
+        g[lane] = st[lane];
+        if (lane < 32) g[64 + lane] = st[64 + lane];
+    }
+}
+
+void launch_warp(hipStream_t s, bool f32, const uint8_t* src, const WarpArgs& a, void* g0, float* w0)
+{
+    dim3 grid(a.wcols / 64, a.wrows / 4), block(256);
+    if (f32) hipLaunchKernelGGL(k_warp<true>, grid, block, 0, s, src, a, g0, w0);
+    else     hipLaunchKernelGGL(k_warp<false>, grid, block, 0, s, src, a, g0, w0);
+}
+
+// ---------------------------------------------------------------- pyrDown
+// dst tile TW x TH pixels per workgroup; horizontal 5-tap into LDS for the
+// 2*TH+3 source rows, then the vertical 5-tap from LDS.
+template <typename T, typename WT, int CN>
+__global__ __launch_bounds__(256) void k_pyrdown(const T* __restrict__ src, int srows, int scols,
+                                                  T* __restrict__ dst, int drows, int dcols,
+                                                  int y0, int y1, int x0, int x1)
+{
+    constexpr int TW = 32, TH = 16, EW = TW * CN, SR = 2 * TH + 3;
+    __shared__ WT hbuf[SR][EW];
+    const int ox = x0 + blockIdx.x * TW, oy = y0 + blockIdx.y * TH;
+    for (int idx = threadIdx.x; idx < SR * EW; idx += 256) {
+        const int r = idx / EW, e = idx - r * EW;
+        const int x = ox + e / CN, k = e % CN;
+        if (x >= x1) continue;
+        const int sy = border_reflect101(2 * oy - 2 + r, srows);
+        const T* s = src + (long)sy * scols * CN + k;
+        int i0 = 2 * x - 2, i1 = 2 * x - 1, i2 = 2 * x, i3 = 2 * x + 1, i4 = 2 * x + 2;
+        if (i0 < 0 || i4 >= scols) {
+            i0 = border_reflect101(i0, scols); i1 = border_reflect101(i1, scols); i2 = border_reflect101(i2, scols);
+            i3 = border_reflect101(i3, scols); i4 = border_reflect101(i4, scols);
+        }
+        hbuf[r][e] = (WT)s[i2 * CN] * 6 + ((WT)s[i1 * CN] + (WT)s[i3 * CN]) * 4 + (WT)s[i0 * CN] + (WT)s[i4 * CN];
+    }
+    __syncthreads();
+    const int vec_end = (dcols * CN / 8) * 8;      // PyrDownVec_32f covers full groups of 8 floats
+    for (int idx = threadIdx.x; idx < TH * EW; idx += 256) {
+        const int r = idx / EW, e = idx - r * EW;
+        const int y = oy + r, x = ox + e / CN;
+        if (y >= y1 || x >= x1) continue;
+        const WT r0 = hbuf[2 * r][e], r1 = hbuf[2 * r + 1][e], r2 = hbuf[2 * r + 2][e], r3 = hbuf[2 * r + 3][e],
+                 r4 = hbuf[2 * r + 4][e];
+        const int ge = ox * CN + e;
+        T o;
+        if constexpr (sizeof(T) == 4) {
+            if (ge < vec_end) {
+                WT a = r0 + r4;
+                WT b = (r1 + r3) + r2;
+                a = a + (r2 + r2);
+                o = (a + b * 4.f) * (1.f / 256);
+            } else
+                o = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
+        } else
+            o = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
+        dst[(long)y * dcols * CN + ge] = o;
+    }
+}
+
+void launch_pyrdown(hipStream_t s, int type, const void* src, int srows, int scols, void* dst,
+                    int y0, int y1, int x0, int x1)
+{
+    const int drows = (srows + 1) / 2, dcols = (scols + 1) / 2;
+    if (y1 <= y0 || x1 <= x0) return;
+    dim3 grid((x1 - x0 + 31) / 32, (y1 - y0 + 15) / 16), block(256);
+    if (type == 0)
+        hipLaunchKernelGGL((k_pyrdown<short, int, 3>), grid, block, 0, s, (const short*)src, srows, scols, (short*)dst, drows, dcols, y0, y1, x0, x1);
+    else if (type == 1)
+        hipLaunchKernelGGL((k_pyrdown<float, float, 3>), grid, block, 0, s, (const float*)src, srows, scols, (float*)dst, drows, dcols, y0, y1, x0, x1);
+    else
+        hipLaunchKernelGGL((k_pyrdown<float, float, 1>), grid, block, 0, s, (const float*)src, srows, scols, (float*)dst, drows, dcols, y0, y1, x0, x1);
+}
+
+// ------------------------------------------------------------------ pyrUp
+// value of pyrUp(src)[y][x][k] for a 2x destination (pyramids.cpp pyrUp_):
+// horizontal  even: s[x-1] + s[x]*6 + s[x+1]   odd: (s[x]+s[x+1])*4
+//   left edge even: s[0]*6 + s[1]*2 ; right edge even: s[n-2] + s[n-1]*7, odd: s[n-1]*8
+// vertical    even: r0 + r1*6 + r2             odd: (r1+r2)*4   rows: -1 -> 1, n -> n-1
+template <typename T, typename WT>
+__device__ __forceinline__ WT up_h(const T* __restrict__ row, int x, int scols)
+{
+    const int sx = x >> 1;
+    if (scols == 1) return (WT)row[0] * 8;
+    if (x & 1) {
+        if (sx == scols - 1) return (WT)row[sx * 3] * 8;
+        return ((WT)row[sx * 3] + (WT)row[(sx + 1) * 3]) * 4;
+    }
+    if (sx == 0) return (WT)row[0] * 6 + (WT)row[3] * 2;
+    if (sx == scols - 1) return (WT)row[(sx - 1) * 3] + (WT)row[sx * 3] * 7;
+    return (WT)row[(sx - 1) * 3] + (WT)row[sx * 3] * 6 + (WT)row[(sx + 1) * 3];
+}
+
+template <typename T, typename WT>
+__device__ __forceinline__ T pyr_up_at(const T* __restrict__ src, int srows, int scols, int y, int x, int k)
+{
+    const int sy = y >> 1;
+    const T* r1 = src + (long)sy * scols * 3 + k;
+    int syn = sy + 1; if (syn >= srows) syn = srows - 1;
+    const T* r2 = src + (long)syn * scols * 3 + k;
+    if (y & 1) return cast_up((up_h<T, WT>(r1, x, scols) + up_h<T, WT>(r2, x, scols)) * 4);
+    int syp = sy - 1; if (syp < 0) syp = srows > 1 ? 1 : 0;
+    const T* r0 = src + (long)syp * scols * 3 + k;
+    return cast_up(up_h<T, WT>(r0, x, scols) + up_h<T, WT>(r1, x, scols) * 6 + up_h<T, WT>(r2, x, scols));
+}
+
+// ------------------------------------------------- Laplacian + tile select
+template <bool F32>
+__global__ __launch_bounds__(256) void k_lap_select(TileLayout lay, int level, const void* __restrict__ giv,
+                                                     const void* __restrict__ gupv, const float* __restrict__ wi,
+                                                     int rows, int cols, const uint64_t* __restrict__ table,
+                                                     int tiles_x, int py0, int px0, int px1, int py1)
+{
+    using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
+    const int x = px0 + blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = py0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= px1 || y >= py1) return;
+    const int sh = 8 - level, ts = kElePixels >> level;
+    const uint64_t ent = table[(y >> sh) * tiles_x + (x >> sh)];
+    if (!ent) return;                                  // tile not owned by this shard
+    char* slot = reinterpret_cast<char*>(ent & ~(uint64_t)1);
+    const bool fresh = ent & 1;
+    const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
+    float* dw = reinterpret_cast<float*>(slot + lay.w_off[level]) + loc;
+    const long pix = (long)y * cols + x;
+    const float sw = wi[pix];
+    if (!fresh && !(sw >= *dw)) return;
+    const T* gi = reinterpret_cast<const T*>(giv) + pix * 3;
+    T* dl = reinterpret_cast<T*>(slot + lay.lap_off[level]) + loc * 3;
+    if (gupv) {
+        const T* gup = reinterpret_cast<const T*>(gupv);
+        const int srows = rows >> 1, scols = cols >> 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) dl[k] = sat_sub(gi[k], pyr_up_at<T, WT>(gup, srows, scols, y, x, k));
+    } else {
+        dl[0] = gi[0]; dl[1] = gi[1]; dl[2] = gi[2];
+    }
+    *dw = sw;
+}
+
+void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const void* g_i, const void* g_up,
+                       const float* w_i, int rows, int cols, const uint64_t* tile_table, int tiles_x,
+                       int ty0, int ty1, int tx0, int tx1)
+{
+    const int ts = kElePixels >> level;
+    const int px0 = tx0 * ts, px1 = tx1 * ts, py0 = ty0 * ts, py1 = ty1 * ts;
+    if (px1 <= px0 || py1 <= py0) return;
+    dim3 grid((px1 - px0 + 63) / 64, (py1 - py0 + 3) / 4), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_lap_select<true>, grid, block, 0, s, lay, level, g_i, g_up, w_i, rows, cols, tile_table, tiles_x, py0, px0, px1, py1);
+    else         hipLaunchKernelGGL(k_lap_select<false>, grid, block, 0, s, lay, level, g_i, g_up, w_i, rows, cols, tile_table, tiles_x, py0, px0, px1, py1);
+}
+
+// ------------------------------------------------------------------ blend
+// strip-set geometry of a neighbour at (dx,dy): level i holds h_i x w_i pixels
+__host__ __device__ inline void strip_dims(int nlev, int level, int dx, int dy, int& w, int& h)
+{
+    const int ts = kElePixels >> level, b = 1 << (nlev - 1 - level);
+    w = dx == 0 ? ts : b; h = dy == 0 ? ts : b;
+}
+
+size_t halo_bytes(const TileLayout& lay, int dx, int dy)
+{
+    size_t n = 0;
+    for (int i = 0; i < lay.nlev; i++) { int w, h; strip_dims(lay.nlev, i, dx, dy, w, h); n += (size_t)w * h; }
+    return n * 3 * (lay.f32 ? 4 : 2);
+}
+
+// Ele::blend's 3x3 assembly (.cpp:93-117): padded level image of side ts+2b.
+template <bool F32>
+__global__ __launch_bounds__(256) void k_blend_gather(TileLayout lay, int level, int border, const BlendSrc* __restrict__ srcs,
+                                                       char* __restrict__ dst, size_t dst_stride)
+{
+    using T = typename Pix<F32>::T;
+    const int ts = kElePixels >> level, side = ts + 2 * border;
+    const int px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= side || py >= side) return;
+    const int z = blockIdx.z;
+    int rx, sx, ry, sy;
+    if (px < border) { rx = 0; sx = ts - border + px; } else if (px < border + ts) { rx = 1; sx = px - border; } else { rx = 2; sx = px - border - ts; }
+    if (py < border) { ry = 0; sy = ts - border + py; } else if (py < border + ts) { ry = 1; sy = py - border; } else { ry = 2; sy = py - border - ts; }
+    const BlendSrc bs = srcs[z * 9 + ry * 3 + rx];
+    T* d = reinterpret_cast<T*>(dst + z * dst_stride) + ((long)py * side + px) * 3;
+    const T* s;
+    if (!bs.is_strip) {
+        s = reinterpret_cast<const T*>(reinterpret_cast<const char*>(bs.base) + lay.lap_off[level]) + ((long)sy * ts + sx) * 3;
+    } else {
+        // packed strips: levels concatenated, each h x w row-major, origin at the strip's corner
+        const int dx = rx - 1, dy = ry - 1;
+        long off = 0;
+        for (int i = 0; i < level; i++) { int w, h; strip_dims(lay.nlev, i, dx, dy, w, h); off += (long)w * h; }
+        int w, h; strip_dims(lay.nlev, level, dx, dy, w, h);
+        const int lx = (rx == 0) ? sx - (ts - border) : sx, ly = (ry == 0) ? sy - (ts - border) : sy;
+        s = reinterpret_cast<const T*>(bs.base) + (off + (long)ly * w + lx) * 3;
+    }
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,
+                         void* dst, size_t dst_stride_bytes, int batch)
+{
+    const int side = (kElePixels >> level) + 2 * border;
+    dim3 grid((side + 63) / 64, (side + 3) / 4, batch), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_blend_gather<true>, grid, block, 0, s, lay, level, border, srcs, (char*)dst, dst_stride_bytes);
+    else         hipLaunchKernelGGL(k_blend_gather<false>, grid, block, 0, s, lay, level, border, srcs, (char*)dst, dst_stride_bytes);
+}
+
+// restoreImageFromLaplacePyr step: dst = pyrUp(src) + dst  (saturating for 16S)
+template <bool F32>
+__global__ __launch_bounds__(256) void k_collapse(char* __restrict__ dst, size_t dst_stride, const char* __restrict__ src,
+                                                   size_t src_stride, int rows, int cols)
+{
+    using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    T* d = reinterpret_cast<T*>(dst + blockIdx.z * dst_stride) + ((long)y * cols + x) * 3;
+    const T* s = reinterpret_cast<const T*>(src + blockIdx.z * src_stride);
+#pragma unroll
+    for (int k = 0; k < 3; k++) d[k] = sat_add(pyr_up_at<T, WT>(s, rows >> 1, cols >> 1, y, x, k), d[k]);
+}
+
+void launch_collapse(hipStream_t s, bool f32, void* dst, size_t dst_stride_bytes, const void* src,
+                     size_t src_stride_bytes, int rows, int cols, int batch)
+{
+    dim3 grid((cols + 63) / 64, (rows + 3) / 4, batch), block(256);
+    if (f32) hipLaunchKernelGGL(k_collapse<true>, grid, block, 0, s, (char*)dst, dst_stride_bytes, (const char*)src, src_stride_bytes, rows, cols);
+    else     hipLaunchKernelGGL(k_collapse<false>, grid, block, 0, s, (char*)dst, dst_stride_bytes, (const char*)src, src_stride_bytes, rows, cols);
+}
+
+__device__ __forceinline__ uint8_t sat_uchar(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// crop the centre 256^2, zero where weights[0]==0 (.cpp:121-126,144), optional 8U view (.cpp:156)
+template <bool F32>
+__global__ __launch_bounds__(256) void k_blend_finish(TileLayout lay, const char* __restrict__ lvl0, size_t stride, int border,
+                                                       const BlendSrc* __restrict__ srcs, char* __restrict__ raw, uint8_t* __restrict__ bgr)
+{
+    using T = typename Pix<F32>::T;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    const int side = kElePixels + 2 * border;
+    const T* s = reinterpret_cast<const T*>(lvl0 + z * stride) + ((long)(y + border) * side + x + border) * 3;
+    const float* w0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(srcs[z * 9 + 4].base) + lay.w_off[0]);
+    const bool zero = w0[y * kElePixels + x] == 0.f;
+    const long o = ((long)z * kElePixels * kElePixels + y * kElePixels + x) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const T v = zero ? (T)0 : s[k];
+        if (raw) reinterpret_cast<T*>(raw)[o + k] = v;
+        if (bgr) {
+            if constexpr (F32) bgr[o + k] = sat_uchar(__float2int_rn(v * 255.f));
+            else bgr[o + k] = sat_uchar(v);
+        }
+    }
+}
+
+void launch_blend_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, size_t stride_bytes, int border,
+                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch)
+{
+    dim3 grid(kElePixels / 64, kElePixels / 4, batch), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_blend_finish<true>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out);
+    else         hipLaunchKernelGGL(k_blend_finish<false>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out);
+}
+
+// ------------------------------------------------------------------- save
+template <bool F32>
+__global__ __launch_bounds__(256) void k_mosaic_gather(TileLayout lay, int level, const uint64_t* __restrict__ table, int wx, int wy,
+                                                        char* __restrict__ dst)
+{
+    using T = typename Pix<F32>::T;
+    const int ts = kElePixels >> level, cols = wx * ts, rows = wy * ts;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const uint64_t ent = table[(y / ts) * wx + x / ts];
+    T* d = reinterpret_cast<T*>(dst) + ((long)y * cols + x) * 3;
+    if (!ent) { d[0] = d[1] = d[2] = (T)0; return; }
+    const T* s = reinterpret_cast<const T*>(reinterpret_cast<const char*>(ent) + lay.lap_off[level]) + ((long)(y % ts) * ts + x % ts) * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+void launch_mosaic_gather(hipStream_t s, const TileLayout& lay, int level, const uint64_t* table, int wx, int wy, void* dst)
+{
+    const int ts = kElePixels >> level;
+    dim3 grid((wx * ts + 63) / 64, (wy * ts + 3) / 4), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_mosaic_gather<true>, grid, block, 0, s, lay, level, table, wx, wy, (char*)dst);
+    else         hipLaunchKernelGGL(k_mosaic_gather<false>, grid, block, 0, s, lay, level, table, wx, wy, (char*)dst);
+}
+
+// 16S -> 8U saturate, background where level-0 weight == 0 (.cpp:838-840)
+template <bool F32>
+__global__ __launch_bounds__(256) void k_save_finish(TileLayout lay, const char* __restrict__ lvl0, const uint64_t* __restrict__ table,
+                                                      int wx, int wy, int bg, uint8_t* __restrict__ bgr)
+{
+    using T = typename Pix<F32>::T;
+    const int cols = wx * kElePixels, rows = wy * kElePixels;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= cols || y >= rows) return;
+    const uint64_t ent = table[(y >> 8) * wx + (x >> 8)];
+    float w = 0.f;
+    if (ent) w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ent) + lay.w_off[0])[(y & 255) * kElePixels + (x & 255)];
+    const long o = ((long)y * cols + x) * 3;
+    const T* s = reinterpret_cast<const T*>(lvl0) + o;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint8_t v;
+        if (w == 0.f) v = sat_uchar(bg);
+        else if constexpr (F32) v = sat_uchar(__float2int_rn(s[k] * 255.f));
+        else v = sat_uchar(s[k]);
+        bgr[o + k] = v;
+    }
+}
+
+void launch_save_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, const uint64_t* table, int wx, int wy,
+                        int bg, uint8_t* bgr)
+{
+    dim3 grid((wx * kElePixels + 63) / 64, (wy * kElePixels + 3) / 4), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_save_finish<true>, grid, block, 0, s, lay, (const char*)lvl0, table, wx, wy, bg, bgr);
+    else         hipLaunchKernelGGL(k_save_finish<false>, grid, block, 0, s, lay, (const char*)lvl0, table, wx, wy, bg, bgr);
+}
+
+// ------------------------------------------------------------- halo pack
+template <bool F32>
+__global__ __launch_bounds__(256) void k_halo_pack(TileLayout lay, const char* __restrict__ slot, int dx, int dy, char* __restrict__ out)
+{
+    using T = typename Pix<F32>::T;
+    // one launch covers all levels: blockIdx.y = level
+    const int level = blockIdx.y;
+    const int ts = kElePixels >> level, b = 1 << (lay.nlev - 1 - level);
+    int w, h; strip_dims(lay.nlev, level, dx, dy, w, h);
+    long off = 0;
+    for (int i = 0; i < level; i++) { int ww, hh; strip_dims(lay.nlev, i, dx, dy, ww, hh); off += (long)ww * hh; }
+    // the neighbour at (dx,dy) of the requesting tile hands over the edge facing it:
+    // dx=-1 (left neighbour) -> its right-most b columns, dx=+1 -> its left-most b columns
+    const int sx0 = dx < 0 ? ts - b : 0, sy0 = dy < 0 ? ts - b : 0;
+    const T* s = reinterpret_cast<const T*>(slot + lay.lap_off[level]);
+    T* d = reinterpret_cast<T*>(out) + off * 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int ly = i / w, lx = i - ly * w;
+        const long sp = ((long)(sy0 + ly) * ts + sx0 + lx) * 3;
+        d[(long)i * 3] = s[sp]; d[(long)i * 3 + 1] = s[sp + 1]; d[(long)i * 3 + 2] = s[sp + 2];
+    }
+}
+
+void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, int dx, int dy, void* out)
+{
+    dim3 grid(32, lay.nlev), block(256);
+    if (lay.f32) hipLaunchKernelGGL(k_halo_pack<true>, grid, block, 0, s, lay, (const char*)slot, dx, dy, (char*)out);
+    else         hipLaunchKernelGGL(k_halo_pack<false>, grid, block, 0, s, lay, (const char*)slot, dx, dy, (char*)out);
+}
+
+// ------------------------------------------------------------------ misc
+TileLayout make_layout(int band_num, bool f32)
+{
+    TileLayout l{};
+    l.nlev = band_num + 1; l.f32 = f32 ? 1 : 0;
+    uint32_t off = 0;
+    const int es = f32 ? 4 : 2;
+    for (int i = 0; i < l.nlev; i++) { l.lap_off[i] = off; const uint32_t n = (kElePixels >> i) * (kElePixels >> i); off += ((n * 3 * es + 255) / 256) * 256; }
+    for (int i = 0; i < l.nlev; i++) { l.w_off[i] = off;   const uint32_t n = (kElePixels >> i) * (kElePixels >> i); off += ((n * 4 + 255) / 256) * 256; }
+    l.slot_bytes = off;
+    return l;
+}
+
+const char* kernel_name(int id)
+{
+    static const char* n[K_COUNT] = { "warp", "pyrdown_img", "pyrdown_w", "lap_select", "blend_gather", "collapse",
+                                      "blend_finish", "mosaic_gather", "save_finish" };
+    return (id >= 0 && id < K_COUNT) ? n[id] : "?";
+}
+
+}  // namespace pf

@@ -1,0 +1,84 @@
+// kernels.hpp -- launch wrappers of the gfx950 kernels (kernels.hip).
+//
+// Data layout in HBM:
+//   frame      : BGR8 interleaved, row step in bytes (as handed to feed()).
+//   canvas G_i : per-frame Gaussian level i, interleaved 3 x {int16|float},
+//                row-major, (tilesY*256 >> i) x (tilesX*256 >> i).
+//   canvas W_i : per-frame weight level i, float, same extent.
+//   tile slot  : one contiguous block per mosaic tile:
+//                [lap_0 | lap_1 | ... | lap_L | w_0 | ... | w_L], level i is a
+//                packed (256>>i)^2 image; offsets in TileLayout.
+//   tile table : per frame, tilesX*tilesY uint64 = slot base address | fresh bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+
+namespace pf {
+
+constexpr int kElePixels = 256;
+constexpr int kMaxLevels = 9;
+
+struct TileLayout {
+    int      nlev;          // bandNum + 1
+    int      f32;           // 0: 16SC3 pyramids, 1: 32FC3
+    uint32_t lap_off[kMaxLevels];   // byte offsets inside a slot
+    uint32_t w_off[kMaxLevels];
+    uint32_t slot_bytes;
+};
+
+TileLayout make_layout(int band_num, bool f32);
+
+struct WarpArgs {
+    double M[9];            // destination -> source map (inverse of the frame's homography)
+    int    srows, scols;
+    long   sstep;           // source row step, bytes
+    int    crows, ccols;    // canvas extent
+    int    y_off, x_off;    // canvas-space origin of the rendered window (shard sub-canvas)
+    int    wrows, wcols;    // window extent (multiple of 4 rows / 64 cols)
+    float  xc, yc, dis_max; // radial weight constants (MultiBandMap2DCPU.cpp:404-406)
+    int    weight_type;
+};
+
+// a source of blend() pixels: a tile slot or a packed halo strip set
+struct BlendSrc {
+    const void* base;       // nullptr = absent
+    int         is_strip;
+};
+
+// kernel ids for the profile table
+enum KernelId { K_WARP = 0, K_PYRDOWN_IMG, K_PYRDOWN_W, K_LAP_SELECT, K_BLEND_GATHER, K_COLLAPSE,
+                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_COUNT };
+const char* kernel_name(int id);
+
+void launch_warp(hipStream_t s, bool f32, const uint8_t* src, const WarpArgs& a, void* g0, float* w0);
+
+// type: 0 = 16SC3, 1 = 32FC3, 2 = 32FC1.  Canvas-level pyrDown with the window
+// (shard) restricted to dst rows [y0,y1) x cols [x0,x1).
+void launch_pyrdown(hipStream_t s, int type, const void* src, int srows, int scols, void* dst,
+                    int y0, int y1, int x0, int x1);
+
+// Laplacian level `level` (G_i - pyrUp(G_{i+1}); top level: G_L) fused with the
+// per-tile max-weight select (MultiBandMap2DCPU.cpp:496-551).
+void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const void* g_i, const void* g_up,
+                       const float* w_i, int rows, int cols, const uint64_t* tile_table, int tiles_x,
+                       int ty0, int ty1, int tx0, int tx1);
+
+// blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
+void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,
+                         void* dst, size_t dst_stride_bytes, int batch);
+void launch_collapse(hipStream_t s, bool f32, void* dst, size_t dst_stride_bytes, const void* src,
+                     size_t src_stride_bytes, int rows, int cols, int batch);
+void launch_blend_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, size_t stride_bytes, int border,
+                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch);
+
+// save(): paste tiles of a dense (wx x wy) table into one mosaic level, then collapse, then finish
+void launch_mosaic_gather(hipStream_t s, const TileLayout& lay, int level, const uint64_t* table, int wx, int wy, void* dst);
+void launch_save_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, const uint64_t* table, int wx, int wy,
+                        int bg, uint8_t* bgr);
+
+// halo strip pack (multi-GPU blend): writes the strip set a neighbour at (dx,dy) needs
+size_t halo_bytes(const TileLayout& lay, int dx, int dy);
+void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, int dx, int dy, void* out);
+
+}  // namespace pf
