@@ -114,6 +114,18 @@ int     pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap);
 int     pf_normalize_using_weight_map(const float* weight, float* src3, size_t npix);
 int     pf_mul_weight_map(const float* weight, float* src3, size_t npix);
 
+/* --- stateless host geometry (no device needed) ---------------------------
+ * The fp64 pose algebra the path uses, in the reference's operation order:
+ * SE3::inverse / operator* (GSLAM/GSLAM/core/SE3.h:70-90), SO3*Point (SO3.h:445-450),
+ * the four-corner ground footprint with the 0.4 gate (.cpp:324-347; pose in plane
+ * coordinates, returns 0 when the frame is rejected) and the homography set-up of
+ * cv::getPerspectiveTransform (.cpp:441). */
+void    pf_se3_inverse(const double a[7], double out[7]);
+void    pf_se3_mul(const double a[7], const double b[7], double out[7]);
+void    pf_so3_rotate(const double q[4], const double p[3], double out[3]);
+int     pf_footprint(const double cam[6], const double pose_plane[7], double pts8[8]);
+void    pf_perspective_transform(const float src8[8], const float dst8[8], double M[9]);
+
 /* --- multi-GPU seam exchange (no reference counterpart) ------ */
 /* owner rank of a tile under the spatial hash */
 int     pf_tile_owner(const pf_options* o, int ix, int iy);
@@ -132,7 +144,7 @@ int     pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in);
 
 /* --- measurement -------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the map's own stream.  mode 0 = off,
- * 1 = every kernel.  Read returns count kernels; name[i] static strings.   */
+ * 1 = every kernel, 2+k = only kernel k (index in pf_profile_read order).  Read returns count kernels; name[i] static strings.   */
 int     pf_profile_enable(pf_map* m, int mode);
 int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
                         double* alg_bytes);

@@ -50,6 +50,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libpifusion.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME, different file name).
+    # Loading torch first makes the dynamic linker hand that one runtime to this library
+    # too; the other order ends with two HIP runtimes in the process and torch blind.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.pf_default_options.argtypes = [C.POINTER(Options)]; L.pf_default_options.restype = None
@@ -90,6 +97,11 @@ def lib():
     return L
 
 
+def _pose(p):
+    a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
 def default_options(**kw):
     o = Options()
     lib().pf_default_options(C.byref(o))
@@ -100,13 +112,35 @@ def default_options(**kw):
     return o
 
 
+def se3_inverse(a):
+    a, pa = _pose(a); o = np.zeros(7); lib().pf_se3_inverse(pa, o.ctypes.data_as(C.POINTER(C.c_double))); return o
+
+
+def se3_mul(a, b):
+    a, pa = _pose(a); b, pb = _pose(b); o = np.zeros(7)
+    lib().pf_se3_mul(pa, pb, o.ctypes.data_as(C.POINTER(C.c_double))); return o
+
+
+def so3_rotate(q, p):
+    q, pq = _pose(q); p, pp = _pose(p); o = np.zeros(3)
+    lib().pf_so3_rotate(pq, pp, o.ctypes.data_as(C.POINTER(C.c_double))); return o
+
+
+def footprint(cam, pose_plane):
+    c, pc = _pose(cam); p, pp = _pose(pose_plane); o = np.zeros(8)
+    ok = lib().pf_footprint(pc, pp, o.ctypes.data_as(C.POINTER(C.c_double)))
+    return o.reshape(4, 2) if ok else None
+
+
+def perspective_transform(src, dst):
+    s = np.ascontiguousarray(src, dtype=np.float32).reshape(8); d = np.ascontiguousarray(dst, dtype=np.float32).reshape(8)
+    M = np.zeros(9)
+    lib().pf_perspective_transform(s.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p))
+    return M.reshape(3, 3)
+
+
 def tile_owner(opt, ix, iy):
     return lib().pf_tile_owner(C.byref(opt), ix, iy)
-
-
-def _pose(p):
-    a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
-    return a, a.ctypes.data_as(C.POINTER(C.c_double))
 
 
 class Map2D:

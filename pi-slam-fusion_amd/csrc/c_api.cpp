@@ -90,6 +90,18 @@ int pf_mul_weight_map(const float* weight, float* src3, size_t npix)
     return 1;
 }
 
+static pf::Pose to_pose(const double a[7]) { return pf::pose_from7(a); }
+static void from_pose(const pf::Pose& p, double o[7]) { std::memcpy(o, p.t, 24); std::memcpy(o + 3, p.q, 32); }
+void pf_se3_inverse(const double a[7], double out[7]) { from_pose(pf::inverse(to_pose(a)), out); }
+void pf_se3_mul(const double a[7], const double b[7], double out[7]) { from_pose(pf::mul(to_pose(a), to_pose(b)), out); }
+void pf_so3_rotate(const double q[4], const double p[3], double out[3]) { pf::rotate(q, p, out); }
+int pf_footprint(const double cam[6], const double pose_plane[7], double pts8[8])
+{
+    const pf::Camera c{ cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], 1. / cam[2], 1. / cam[3] };
+    return pf::footprint(c, to_pose(pose_plane), pts8) ? 1 : 0;
+}
+void pf_perspective_transform(const float src8[8], const float dst8[8], double M[9]) { pf::perspective_transform(src8, dst8, M); }
+
 int pf_tile_owner(const pf_options* o, int ix, int iy) { return o ? pf::tile_owner(o->shard_count, o->shard_block, ix, iy) : 0; }
 size_t pf_halo_bytes(pf_map* m, int dx, int dy) { return m ? m->impl.halo_bytes_for(dx, dy) : 0; }
 int pf_halo_pack(pf_map* m, int ix, int iy, int dx, int dy, void* dev_out) { return m && dev_out && m->impl.halo_pack(ix, iy, dx, dy, dev_out); }

@@ -136,7 +136,8 @@ void FusionMap::profile_enable(int mode) { std::lock_guard<std::mutex> l(mu_); p
 
 void FusionMap::prof_begin(int id, double bytes)
 {
-    if (!prof_mode_) return;
+    prof_on_ = prof_mode_ == 1 || prof_mode_ == 2 + id;      // mode 2+k: only kernel k
+    if (!prof_on_) return;
     auto get = [&]() { hipEvent_t e; if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); } else (void)hipEventCreate(&e); return e; };
     prof_cur_ = { id, get(), get(), bytes };
     (void)hipEventRecord(prof_cur_.a, stream_);
@@ -144,7 +145,7 @@ void FusionMap::prof_begin(int id, double bytes)
 
 void FusionMap::prof_end()
 {
-    if (!prof_mode_) return;
+    if (!prof_on_) return;
     (void)hipEventRecord(prof_cur_.b, stream_);
     prof_pending_.push_back(prof_cur_);
     if (prof_pending_.size() > 4096) { (void)hipStreamSynchronize(stream_); prof_harvest(); }

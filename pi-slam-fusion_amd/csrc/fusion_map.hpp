@@ -153,7 +153,7 @@ private:
 
     // profile
     struct ProfRec { int id; hipEvent_t a, b; double bytes; };
-    int prof_mode_ = 0;
+    int prof_mode_ = 0; bool prof_on_ = false;
     std::vector<ProfRec> prof_pending_;
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};

@@ -1,0 +1,88 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/pifusion.h declares; the stateless host geometry entry points agree with the
+vectors generated from the reference's own SE3 headers (tests/golden/se3_vectors.json,
+made by tests/golden/make_se3_vectors.py from oracle/_ref/se3_ref)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pifusion.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pf):
+    lib = ctypes.CDLL(pf.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+
+
+def test_options_keys_follow_svar_names(pf):
+    o = pf.default_options()
+    assert (o.band_number, o.force_float, o.high_quality_show, o.weight_type, o.scale, o.max_queue) == (5, 0, 1, 0, 1.0, 20)
+    L = pf.lib()
+    assert L.pf_options_set(ctypes.byref(o), b"MultiBandMap2DCPU.BandNumber", b"7") == 1 and o.band_number == 7
+    assert L.pf_options_set(ctypes.byref(o), b"Map2D.Scale", b"0.5") == 1 and o.scale == 0.5
+    assert L.pf_options_set(ctypes.byref(o), b"MultiBandMap2DCPU.ForceFloat", b"1") == 1 and o.force_float == 1
+    assert L.pf_options_set(ctypes.byref(o), b"No.Such.Key", b"1") == 0
+
+
+def test_no_device_fails_loudly(pf):
+    """The product path has no CPU fallback: on a box without a GPU create() raises."""
+    import pytest
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError):
+        pf.Map2D.create(pf.TypeMultiBandCPU, False)
+
+
+def test_tile_owner_spatial_hash(pf):
+    o = pf.default_options(shard_count=8, shard_block=4)
+    owners = {(x, y): pf.tile_owner(o, x, y) for x in range(-16, 16) for y in range(-16, 16)}
+    assert set(owners.values()) == set(range(8))
+    for (x, y), r in owners.items():        # constant inside a 4x4 cell, negative coords use floor division
+        assert r == owners[((x // 4) * 4, (y // 4) * 4)]
+    assert pf.tile_owner(pf.default_options(), 5, -3) == 0
+
+
+def test_host_geometry_matches_reference_headers(pf, orc):
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "se3_vectors.json")))
+    cam = vec["cam"]
+    n_ok = 0
+    for c in vec["cases"]:
+        for impl in (pf, orc):
+            assert np.array_equal(impl.se3_inverse(c["plane"]), np.array(c["plane_inv"]))
+            local = impl.se3_mul(impl.se3_inverse(c["plane"]), c["world"])
+            assert np.array_equal(local, np.array(c["local"]))
+            assert np.array_equal(impl.so3_rotate(c["local"][3:], c["probe"]), np.array(c["rot"]))
+        fp = pf.footprint(cam, c["local"])
+        assert (fp is not None) == bool(c["ok"])
+        if c["ok"]:
+            n_ok += 1
+            assert np.array_equal(fp.reshape(-1), np.array(c["pts"]))
+    assert 0 < n_ok < len(vec["cases"])
+
+
+def test_perspective_transform_same_in_product_and_oracle(pf, orc):
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        src = np.array([0, 0, 4000, 0, 0, 3000, 4000, 3000], np.float32)
+        dst = (src.reshape(4, 2) * rng.uniform(0.8, 1.2) + rng.uniform(-300, 300, (4, 2))).astype(np.float32).reshape(-1)
+        Mp, Mo = pf.perspective_transform(src, dst), orc.get_perspective_transform(src, dst)
+        assert np.array_equal(Mp, Mo)
+        for i in range(4):      # it is a homography through the four correspondences
+            v = Mp @ np.array([src[2 * i], src[2 * i + 1], 1.0])
+            assert np.allclose(v[:2] / v[2], dst[2 * i:2 * i + 2], atol=1e-6)

@@ -1,0 +1,206 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+on the same seeded inputs.  Bar: bit-exact for the int16 pyramids, the fp32 weights
+and -- since the kernels keep the oracle's operation order -- the fp32 pyramids too
+(the north star allows 1 ULP per band; the tests assert 0 and report ULPs on failure).
+Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:288-558 (feed/renderFrame),
+:77-146 (Ele::blend), :779-847 (save)."""
+import numpy as np
+import pytest
+
+from helpers import compare_maps, jitter_poses, workloads, map_digest, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(pf, orc, cam, poses, frames, n_prepare=None, **opt):
+    wl = workloads()
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, **opt)
+    o = orc.OracleMap(band_num=opt.get("band_number", 5), force_float=opt.get("force_float", 0),
+                      weight_type=opt.get("weight_type", 0), high_quality=opt.get("high_quality_show", 1),
+                      bg_color=opt.get("bg_color", 0), resolution=opt.get("resolution", 0.0), scale=opt.get("scale", 1.0))
+    prep = poses[:n_prepare] if n_prepare else poses
+    assert g.prepare(wl.IDENTITY_PLANE, cam, prep) == o.prepare(wl.IDENTITY_PLANE, cam, prep) == True
+    for img, p in zip(frames, poses):
+        assert g.feed(img, p) == o.feed(img, p)
+    assert g.sync()
+    assert g.grid() == o.grid()
+    return g, o
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+@pytest.mark.parametrize("content", ["noise", "smooth"])
+def test_cfg1_plumbing(pf, orc, force_float, content):
+    """BASELINE.json configs[0]: 10 synthetic 640x480 frames, identity rotation."""
+    wl = workloads()
+    cam, poses = wl.cfg1()
+    gen = wl.noise_frame if content == "noise" else wl.smooth_frame
+    frames = [gen(480, 640, k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, force_float=force_float)
+    assert compare_maps(g, o) == []
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+@pytest.mark.parametrize("bands", [1, 3, 5, 7])
+def test_perspective_and_spread(pf, orc, force_float, bands):
+    """Rotated / tilted frames; grid prepared from 2 poses so later frames hit spreadMap
+    (.cpp:360-379, 561-604); band counts on both sides of the SSE-tail boundary."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(9, seed=7 + bands)
+    frames = [wl.noise_frame(480, 640, 100 + k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, n_prepare=2, force_float=force_float, band_number=bands)
+    assert compare_maps(g, o) == []
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_camera_above_plane_weight_type_scale(pf, orc, force_float):
+    """t.z > 0 branch of the down-look gate (.cpp:335-336), WeightType=1 (.cpp:415), Map2D.Scale=0.5."""
+    wl = workloads()
+    cam = [320, 240, 260, 250, 158.5, 121.25]
+    poses = jitter_poses(6, seed=3, step=(11.0, 5.0), height=60.0, below=False)
+    frames = [wl.smooth_frame(240, 320, k) ^ wl.noise_frame(240, 320, k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, force_float=force_float, weight_type=1, scale=0.5)
+    assert compare_maps(g, o) == []
+
+
+def test_rejections(pf, orc):
+    """bool-return convention (.cpp:290, 319-323, 340-343)."""
+    wl = workloads()
+    cam, poses = wl.cfg1(3)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    img = wl.noise_frame(480, 640, 0)
+    assert g.feed(img, poses[0]) is False                       # before prepare
+    assert g.prepare(wl.IDENTITY_PLANE, cam, [[0, 0, -5, 0, 0, 0, 1], [0, 0, 5, 0, 0, 0, 1]]) is False   # z straddles 0
+    assert g.prepare(wl.IDENTITY_PLANE, [640, 480, 0, 500, 320, 240], poses) is False
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses)
+    assert g.feed(wl.noise_frame(240, 320, 0), poses[0]) is False  # wrong size
+    assert g.feed(np.zeros((480, 640, 4), np.uint8), poses[0]) is False  # wrong type
+    s = np.sin(np.radians(80) / 2); c = np.cos(np.radians(80) / 2)
+    assert g.feed(img, [0, 0, -100, s, 0, 0, c]) is False       # oblique view
+    assert g.feed(img, poses[0]) is True
+    assert g.stats()["rendered"] == 1
+    assert pf.Map2D.create(pf.NoType) is None and pf.Map2D.create(pf.TypeRender) is None
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_blend_and_save(pf, orc, force_float):
+    """Ele::blend with and without the full 3x3 neighbourhood, updateTexture's 8U view, save()."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(8, seed=21, step=(25.0, 22.0), yaw_deg=40)
+    frames = [wl.smooth_frame(480, 640, k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, force_float=force_float, bg_color=37)
+    assert compare_maps(g, o) == []
+    tiles = o.tiles()
+    n_full = 0
+    for (ix, iy) in tiles:
+        full = all((ix + dx, iy + dy) in tiles for dx in (-1, 0, 1) for dy in (-1, 0, 1))
+        n_full += full
+        assert np.array_equal(g.blend_tile_raw(ix, iy), o.blend_tile_raw(ix, iy)), (ix, iy, full)
+        assert np.array_equal(g.blend_tile(ix, iy), o.blend_tile(ix, iy)), (ix, iy, full)
+    assert 0 < n_full < len(tiles)
+    changed, imgs = g.blend_changed()
+    assert sorted(changed) == sorted(tiles)
+    for (ix, iy), im in zip(changed, imgs):
+        assert np.array_equal(im, o.blend_tile(ix, iy))
+    assert g.blend_changed()[0] == []                           # Ischanged cleared (.cpp:186)
+    (gs, gorg), (os_, oorg) = g.save_to_memory(), o.save()
+    assert gorg == oorg and np.array_equal(gs, os_)
+    assert g.blend_tile(10 ** 6, 0) is None
+
+
+def test_low_quality_show_blends_alone(pf, orc):
+    wl = workloads()
+    cam, poses = wl.cfg1(6, step=30.0)
+    frames = [wl.noise_frame(480, 640, k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, high_quality_show=0)
+    for (ix, iy) in o.tiles():
+        assert np.array_equal(g.blend_tile_raw(ix, iy), o.blend_tile_raw(ix, iy))
+
+
+def test_threaded_feed_equals_synchronous(pf, orc):
+    """thread=true: queue (cap 20, drop-oldest, .cpp:298-304) + render thread; prepare frames are
+    rendered first (Map2D.cpp:42).  With no overload the tiles equal the synchronous run."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(12, seed=5)
+    frames = [wl.noise_frame(480, 640, 300 + k) for k in range(len(poses))]
+    gt = pf.Map2D.create(pf.TypeMultiBandCPU, True)
+    assert gt.prepare(wl.IDENTITY_PLANE, cam, poses[:3], images=frames[:3])
+    for img, p in zip(frames[3:], poses[3:]):
+        assert gt.feed(img, p)
+    assert gt.sync() and gt.queueSize() == 0
+    gs = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert gs.prepare(wl.IDENTITY_PLANE, cam, poses[:3])
+    for img, p in zip(frames, poses):
+        assert gs.feed(img, p)
+    gs.sync()
+    assert gt.stats()["dropped"] == 0 and gt.stats()["rendered"] == len(poses)
+    assert map_digest(gt) == map_digest(gs)
+
+
+def test_queue_overflow_drops_oldest(pf):
+    wl = workloads()
+    cam, poses = wl.cfg1(4)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, True, max_queue=2)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses)
+    img = wl.noise_frame(480, 640, 0)
+    for k in range(40):
+        assert g.feed(img, poses[k % 4])
+        assert g.queueSize() <= 2
+    g.sync()
+    st = g.stats()
+    assert st["rendered"] + st["dropped"] == 40
+
+
+def test_device_resident_feed_and_idempotence(pf):
+    """pf_feed_device (frame already in HBM) equals pf_feed; feeding the same frame twice
+    leaves every tile unchanged (ties resolve to the newest, identical, frame: .cpp:521)."""
+    torch = pytest.importorskip("torch")
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(5, seed=11)
+    frames = [wl.noise_frame(480, 640, 40 + k) for k in range(len(poses))]
+    a = pf.Map2D.create(pf.TypeMultiBandCPU, False); b = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    for f, d, p in zip(frames, dev, poses):
+        assert a.feed(f, p)
+        assert b.feed_device(d.data_ptr(), 480, 640, p)
+    a.sync(); b.sync()
+    da = map_digest(a)
+    assert da == map_digest(b)
+    assert a.feed(frames[-1], poses[-1]); a.sync()
+    assert map_digest(a) == da
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_full_size_frame_against_oracle(pf, orc, force_float):
+    """BASELINE.json configs[1] geometry: one 4000x3000 frame, 5 bands, vs the oracle (seconds on CPU)."""
+    wl = workloads()
+    cam, poses = wl.cfg2(3)
+    frame = wl.noise_frame(3000, 4000, 9)
+    g, o = run_pair(pf, orc, cam, poses[:1], [frame], force_float=force_float)
+    assert len(o.tiles()) >= 200
+    assert compare_maps(g, o) == []
+
+
+def test_full_size_properties(pf):
+    """Size-independent properties at BASELINE's full frame size, no oracle involved:
+    a constant-colour frame has zero Laplacian bands below the top and the constant on top
+    wherever the pyramid support lies inside the footprint; blend of it returns the constant."""
+    wl = workloads()
+    cam, poses = wl.cfg2(2)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses)
+    frame = np.full((3000, 4000, 3), 77, np.uint8)
+    assert g.feed(frame, poses[0]) and g.sync()
+    tiles = g.tiles()
+    xs = sorted({t[0] for t in tiles}); ys = sorted({t[1] for t in tiles})
+    cx, cy = xs[len(xs) // 2], ys[len(ys) // 2]          # a tile in the middle of the footprint
+    for lv in range(g.num_levels):
+        lap, w = g.tile_level(cx, cy, lv)
+        assert (w > 0).all()
+        assert (lap == (77 if lv == g.num_levels - 1 else 0)).all()
+    assert (g.blend_tile(cx, cy) == 77).all()

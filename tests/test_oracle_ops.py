@@ -1,0 +1,253 @@
+"""Pins the CPU oracle (oracle/oracle.c) op by op.  The reference holds no tests or
+golden vectors for this path and OpenCV 2.4.9 is absent (parity unpinned at
+the OpenCV boundary), so each op is checked against (i) hand-derived known answers and
+(ii) an independent numpy restatement of the published 2.4.9 rule written here."""
+import numpy as np
+import pytest
+
+
+# ---------------------------------------------------------------- independent numpy restatements
+def np_pyr_down_int(src):
+    """5x5 [1 4 6 4 1]^2, REFLECT_101, ((v+128)>>8) -- exact integer arithmetic."""
+    s = src.astype(np.int64)
+    p = np.pad(s, ((2, 2), (2, 2), (0, 0)), mode="reflect")
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    h = sum(k[j] * p[:, j:j + s.shape[1]:1] for j in range(5))[:, ::2]
+    h = h[:, :(s.shape[1] + 1) // 2]
+    v = sum(k[j] * h[j:j + s.shape[0]] for j in range(5))[::2][:(s.shape[0] + 1) // 2]
+    return ((v + 128) >> 8).astype(np.int16)
+
+
+def np_pyr_up_int(src):
+    """pyrUp to 2x: even = p[x-1]+6p[x]+p[x+1], odd = 4(p[x]+p[x+1]); index -1 -> 1, n -> n-1."""
+    s = src.astype(np.int64)
+
+    def up_axis(a, axis):
+        a = np.moveaxis(a, axis, 0)
+        n = a.shape[0]
+        prev = a[[1 if n > 1 else 0] + list(range(0, n - 1))]
+        nxt = a[list(range(1, n)) + [n - 1]]
+        out = np.empty((2 * n,) + a.shape[1:], np.int64)
+        out[0::2] = prev + 6 * a + nxt
+        out[1::2] = 4 * (a + nxt)
+        return np.moveaxis(out, 0, axis)
+
+    v = up_axis(up_axis(s, 1), 0)
+    return ((v + 32) >> 6).astype(np.int16)
+
+
+def np_warp_linear_reflect(src, M0, drows, dcols, as_float):
+    """warpPerspective LINEAR/REFLECT with the 64-wide block-relative coordinates, vectorised."""
+    M = np.linalg.inv(np.asarray(M0, np.float64))      # only used with exactly invertible test matrices
+    srows, scols, cn = src.shape
+    y, x = np.mgrid[0:drows, 0:dcols]
+    bw0 = min(1024 // min(16, drows), dcols)
+    xb = (x // bw0) * bw0; x1 = x - xb
+    X0 = M[0, 0] * xb + M[0, 1] * y + M[0, 2]
+    Y0 = M[1, 0] * xb + M[1, 1] * y + M[1, 2]
+    W0 = M[2, 0] * xb + M[2, 1] * y + M[2, 2]
+    W = W0 + M[2, 0] * x1
+    W = np.where(W != 0, 32.0 / np.where(W != 0, W, 1), 0.0)
+    X = np.rint(np.clip((X0 + M[0, 0] * x1) * W, -2 ** 31, 2 ** 31 - 1)).astype(np.int64)
+    Y = np.rint(np.clip((Y0 + M[1, 0] * x1) * W, -2 ** 31, 2 ** 31 - 1)).astype(np.int64)
+    sx = np.clip(X >> 5, -32768, 32767); sy = np.clip(Y >> 5, -32768, 32767)
+    fx = ((X & 31).astype(np.float32) * np.float32(1 / 32)); fy = ((Y & 31).astype(np.float32) * np.float32(1 / 32))
+
+    def refl(p, n):
+        p = np.mod(p, 2 * n)
+        return np.where(p < n, p, 2 * n - 1 - p)
+
+    x0, x1_, y0, y1 = refl(sx, scols), refl(sx + 1, scols), refl(sy, srows), refl(sy + 1, srows)
+    one = np.float32(1)
+    w = [(one - fy) * (one - fx), (one - fy) * fx, fy * (one - fx), fy * fx]
+    s = src.astype(np.float32)
+    out = np.empty((drows, dcols, cn), np.float32)
+    for k in range(cn):
+        t = s[y0, x0, k] * w[0]
+        t = t + s[y0, x1_, k] * w[1]
+        t = t + s[y1, x0, k] * w[2]
+        t = t + s[y1, x1_, k] * w[3]
+        out[:, :, k] = t
+    if as_float:
+        return out
+    return np.clip(np.rint(out.astype(np.float64)), -32768, 32767).astype(np.int16)
+
+
+# ---------------------------------------------------------------- pyrDown / pyrUp
+def test_pyr_down_known_answers(orc):
+    c = np.full((8, 8, 3), 100, np.int16)
+    assert (orc.pyr_down(c) == 100).all()                           # DC preserved: 256*100/256
+    imp = np.zeros((9, 9, 1), np.int16); imp[4, 4, 0] = 256
+    d = orc.pyr_down(imp)
+    assert d.shape == (5, 5, 1)
+    assert np.array_equal(d[:, :, 0], np.pad(np.outer([1, 6, 1], [1, 6, 1]), 1))   # taps k[4-2y+2]*k[4-2x+2]
+    # (v+128)>>8 on negatives is an arithmetic shift, not a round-toward-zero divide
+    neg = np.full((4, 4, 1), -1, np.int16)
+    assert (orc.pyr_down(neg) == -1).all()                          # (-256+128)>>8 = -1
+    # REFLECT_101 at the left edge: taps -2,-1 -> 2,1
+    row = np.arange(8, dtype=np.int16).reshape(1, 8, 1) * 16
+    d = orc.pyr_down(np.repeat(row, 4, axis=0))
+    s = row[0, :, 0].astype(int)
+    v0 = 16 * (6 * s[0] + 4 * (s[1] + s[1]) + s[2] + s[2])          # x=0, vertical sum of a constant column = 16*
+    assert d[0, 0, 0] == (v0 + 128) >> 8
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 3), (10, 14, 1), (7, 9, 3), (2, 2, 3), (32, 8, 1)])
+def test_pyr_down_16s_vs_numpy(orc, shape):
+    rng = np.random.RandomState(sum(shape))
+    a = rng.randint(-300, 600, shape).astype(np.int16)
+    assert np.array_equal(orc.pyr_down(a), np_pyr_down_int(a))
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 3), (5, 7, 1), (1, 1, 3), (1, 4, 1), (4, 1, 3), (2, 2, 1), (16, 3, 3)])
+def test_pyr_up_16s_vs_numpy(orc, shape):
+    rng = np.random.RandomState(sum(shape) + 1)
+    a = rng.randint(-300, 600, shape).astype(np.int16)
+    assert np.array_equal(orc.pyr_up(a), np_pyr_up_int(a))
+
+
+def test_pyr_up_known_answers(orc):
+    one = np.array([[[64]]], np.int16)
+    assert (orc.pyr_up(one) == 64).all()                            # n==1: both outputs s*8, (8*8*64+32)>>6
+    row = np.array([[[10], [20], [40]]], np.int16)                  # 1x3
+    u = orc.pyr_up(row)[0, :, 0]
+    # rows: r0=r1=r2 (single row) -> even row = 8*h, so out = (8*h+32)>>6
+    h = np.array([10 * 6 + 20 * 2, (10 + 20) * 4, 10 + 20 * 6 + 40, (20 + 40) * 4, 20 + 40 * 7, 40 * 8])
+    assert np.array_equal(u, (8 * h + 32) >> 6)
+
+
+def test_pyr_down_32f_sse_order_vs_scalar_tail(orc):
+    """Full groups of 8 floats use ((r0+r4)+(r2+r2))+((r1+r3)+r2)*4, the tail the scalar order."""
+    rng = np.random.RandomState(5)
+    a = rng.uniform(0, 1, (12, 22, 1)).astype(np.float32)           # dst width 11: 8 vector + 3 tail
+    d = orc.pyr_down(a)[:, :, 0]
+    p = np.pad(a[:, :, 0], 2, mode="reflect")
+    f = np.float32
+    h = np.empty((16, 11), np.float32)
+    for x in range(11):
+        c = 2 * x + 2
+        h[:, x] = p[:, c] * f(6) + (p[:, c - 1] + p[:, c + 1]) * f(4) + p[:, c - 2] + p[:, c + 2]
+    for y in range(6):
+        r0, r1, r2, r3, r4 = (h[2 * y + j] for j in range(5))
+        vec = (((r0 + r4) + (r2 + r2)) + ((r1 + r3) + r2) * f(4)) * f(1 / 256)
+        sca = (r2 * f(6) + (r1 + r3) * f(4) + r0 + r4) * f(1 / 256)
+        assert np.array_equal(d[y, :8], vec[:8])
+        assert np.array_equal(d[y, 8:], sca[8:])
+    assert not np.array_equal(vec, sca)                             # the two orders do differ somewhere
+
+
+def test_pyr_up_32f_association(orc):
+    rng = np.random.RandomState(6)
+    a = rng.uniform(0, 1, (3, 4, 1)).astype(np.float32)
+    u = orc.pyr_up(a)[:, :, 0]
+    f = np.float32
+    s = a[:, :, 0]
+    h = np.empty((3, 8), np.float32)
+    h[:, 0] = s[:, 0] * f(6) + s[:, 1] * f(2); h[:, 1] = (s[:, 0] + s[:, 1]) * f(4)
+    for x in (1, 2):
+        h[:, 2 * x] = s[:, x - 1] + s[:, x] * f(6) + s[:, x + 1]; h[:, 2 * x + 1] = (s[:, x] + s[:, x + 1]) * f(4)
+    h[:, 6] = s[:, 2] + s[:, 3] * f(7); h[:, 7] = s[:, 3] * f(8)
+    rows = {-1: 1, 0: 0, 1: 1, 2: 2, 3: 2}
+    for y in range(3):
+        r0, r1, r2 = h[rows[y - 1]], h[rows[y]], h[rows[y + 1]]
+        assert np.array_equal(u[2 * y], (r0 + r1 * f(6) + r2) * f(1 / 64))
+        assert np.array_equal(u[2 * y + 1], ((r1 + r2) * f(4)) * f(1 / 64))
+
+
+# ---------------------------------------------------------------- Laplacian pyramid
+@pytest.mark.parametrize("dt", [np.int16, np.float32])
+def test_laplace_pyramid_roundtrip_and_dc(orc, dt):
+    rng = np.random.RandomState(9)
+    if dt == np.int16:
+        img = rng.randint(0, 256, (64, 96, 3)).astype(np.int16)
+    else:
+        img = rng.uniform(0, 1, (64, 96, 3)).astype(np.float32)
+    lv = orc.create_laplace_pyr(img, 4)
+    assert [l.shape[:2] for l in lv] == [(64, 96), (32, 48), (16, 24), (8, 12), (4, 6)]
+    back = orc.restore_from_laplace_pyr(lv)
+    if dt == np.int16:
+        assert np.array_equal(back, img)            # no saturation for 8-bit content -> exact inverse
+    else:
+        assert np.abs(back - img).max() < 1e-5
+    const = np.full((32, 32, 3), 200, dt)
+    lv = orc.create_laplace_pyr(const, 3)
+    assert all((l == 0).all() for l in lv[:-1]) and (lv[-1] == 200).all()
+
+
+def test_laplace_16s_saturating_subtract(orc):
+    img = np.zeros((8, 8, 1), np.int16); img[::2] = 32767; img[1::2] = -32768
+    lv = orc.create_laplace_pyr(img, 1)
+    up = orc.pyr_up(orc.pyr_down(img))
+    assert np.array_equal(lv[0], np.clip(img.astype(np.int32) - up, -32768, 32767).astype(np.int16))
+    assert (lv[0] == 32767).any() or (lv[0] == -32768).any()
+
+
+# ---------------------------------------------------------------- warp
+def test_invert3x3_and_perspective_transform(orc):
+    M = np.array([[1.2, 0.1, 30], [-0.05, 0.9, 12], [1e-5, -2e-5, 1]])
+    assert np.allclose(orc.invert3x3(M) @ M, np.eye(3), atol=1e-12)
+    assert orc.invert3x3(np.zeros((3, 3))) is None
+    src = np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32)
+    dst = np.array([[10, 20], [600, 35], [5, 470], [630, 500]], np.float32)
+    H = orc.get_perspective_transform(src, dst)
+    assert H[2, 2] == 1.0
+    for s, d in zip(src, dst):
+        v = H @ np.array([s[0], s[1], 1.0])
+        assert np.allclose(v[:2] / v[2], d, atol=1e-9)
+
+
+def test_warp_known_answers(orc):
+    rng = np.random.RandomState(2)
+    src = rng.randint(0, 256, (20, 30, 3)).astype(np.int16)
+    I = np.eye(3)
+    assert np.array_equal(orc.warp_linear_reflect(src, I, 20, 30), src)
+    T = np.array([[1, 0, 3], [0, 1, 2], [0, 0, 1.0]])                  # dst(x,y) = src(x-3,y-2)
+    out = orc.warp_linear_reflect(src, T, 20, 30)
+    assert np.array_equal(out[2:, 3:], src[:-2, :-3])
+    assert np.array_equal(out[2:, 0], src[:-2, 2]) and np.array_equal(out[2:, 2], src[:-2, 0])   # REFLECT: -1 -> 0, -3 -> 2
+    Hh = np.array([[1, 0, 0.5], [0, 1, 0], [0, 0, 1.0]])               # half-pixel: mean of two, ties to even
+    a = np.array([[[1], [2], [5], [5]]], np.int16).repeat(2, axis=0)
+    o = orc.warp_linear_reflect(a, Hh, 2, 4)[0, :, 0]
+    assert list(o) == [1, 2, 4, 5]                                      # [refl(1,1)=1, 1.5->2, 3.5->4, 5]
+    w = np.arange(12, dtype=np.float32).reshape(3, 4)
+    n = orc.warp_nearest_const(w, T, 5, 8)[:, :, 0]
+    assert n[2, 3] == w[0, 0] and n[4, 6] == w[2, 3] and n[0, 0] == 0 and n[2, 7] == 0   # CONSTANT 0 outside
+
+
+@pytest.mark.parametrize("as_float", [False, True])
+def test_warp_vs_numpy_restatement(orc, as_float):
+    rng = np.random.RandomState(4)
+    if as_float:
+        src = (rng.randint(0, 256, (37, 53, 3)).astype(np.float32) * np.float32(1 / 255))
+    else:
+        src = rng.randint(0, 256, (37, 53, 3)).astype(np.int16)
+    # exactly representable inverse: M0 = inverse of a dyadic matrix, so numpy's inv and the closed form agree
+    Minv = np.array([[0.75, 0.125, -6.5], [-0.0625, 0.875, 3.25], [0.0, 0.0, 1.0]])
+    M0 = np.linalg.inv(Minv)
+    assert np.allclose(orc.invert3x3(M0), Minv, atol=1e-14)
+    got = orc.warp_linear_reflect(src, M0, 70, 130)
+    # hand the oracle's own inverse to the numpy restatement so that only the warp rule is under test
+    exp = _warp_with_inverse(src, orc.invert3x3(M0), 70, 130, as_float)
+    assert np.array_equal(got, exp)
+
+
+def _warp_with_inverse(src, Minv, drows, dcols, as_float):
+    saved = np.linalg.inv
+    try:
+        np.linalg.inv = lambda a: np.asarray(Minv, np.float64)
+        return np_warp_linear_reflect(src, np.eye(3), drows, dcols, as_float)
+    finally:
+        np.linalg.inv = saved
+
+
+def test_weight_image_formula(orc):
+    w = orc.weight_image(480, 640, 0)
+    xc, yc = np.float32(320), np.float32(240)
+    dm = np.sqrt(xc * xc + yc * yc, dtype=np.float32)
+    i, j = np.mgrid[0:480, 0:640].astype(np.float32)
+    d = (i - yc) * (i - yc) + (j - xc) * (j - xc)
+    e = np.float32(1) - np.sqrt(d, dtype=np.float32) / dm
+    e = np.where(e.astype(np.float64) <= 1e-5, np.float32(1e-5), e)
+    assert np.array_equal(w, e)
+    assert w[0, 0] == np.float32(1e-5) and w[240, 320] == 1.0
+    assert np.array_equal(orc.weight_image(9, 7, 1), np.maximum(orc.weight_image(9, 7, 0) ** 2, np.float32(1e-5)))
