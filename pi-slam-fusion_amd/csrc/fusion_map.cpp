@@ -492,17 +492,21 @@ bool FusionMap::render_frame(const QueuedFrame& f)
 
     // workspace
     const size_t es = lay_.f32 ? 4 : 2;
+    const bool fused = opt_.fused != 0 && L >= 1;
+    const size_t pxb = level_px_bytes(lay_.f32 != 0);
     bool grow = false;
     for (int i = 0; i <= L; i++) {
         const size_t n = (size_t)(crows >> i) * (ccols >> i);
-        if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
+        if (fused) { if (i >= 1 && i < L && gw_[i].cap < n * pxb) grow = true; }
+        else if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
     }
     if (table_cap_ < (size_t)tx * ty) grow = true;
     if (grow) {
         HIP_OK(hipStreamSynchronize(stream_));
         for (int i = 0; i <= L; i++) {
             const size_t n = (size_t)(crows >> i) * (ccols >> i);
-            if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
+            if (fused) { if (i >= 1 && i < L && !gw_[i].reserve(n * pxb)) return false; }
+            else if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
         }
         if (table_cap_ < (size_t)tx * ty) {
             table_cap_ = (size_t)tx * ty * 2;
@@ -546,6 +550,33 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     a.xc = (float)(f.cols / 2); a.yc = (float)(f.rows / 2);
     a.dis_max = std::sqrt(a.xc * a.xc + a.yc * a.yc);
     a.weight_type = opt_.weight_type;
+    if (fused) {
+        // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
+        // wherever the level i+1 launch stages its halo (its region -4 / +3)
+        struct Win C[kMaxLevels];
+        for (int i = L - 1; i >= 0; i--) {
+            const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
+            int x0 = bx0 * ts, x1 = bx1 * ts, y0 = by0 * ts, y1 = by1 * ts;
+            if (i < L - 1) {
+                x0 = std::min(x0, 2 * (C[i + 1].x0 - 4)); x1 = std::max(x1, 2 * (C[i + 1].x1 + 3));
+                y0 = std::min(y0, 2 * (C[i + 1].y0 - 4)); y1 = std::max(y1, 2 * (C[i + 1].y1 + 3));
+            }
+            clampw(x0, x1, cols, C[i].x0, C[i].x1);
+            clampw(y0, y1, rows, C[i].y0, C[i].y1);
+        }
+        const double E = 3 * es + 4;
+        for (int i = 0; i < L; i++) {
+            const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
+            const bool top = (i + 1 == L);
+            // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
+            double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
+            if (i == 0) bytes += 3.0 * f.rows * f.cols;
+            prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes);
+            launch_level(stream_, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
+                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw_[i].p, top ? nullptr : gw_[i + 1].p, dtab);
+            prof_end();
+        }
+    } else {
     const double win0 = (double)a.wrows * a.wcols;
     prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
     launch_warp(stream_, lay_.f32, src, a, g_[0].p, (float*)wgt_[0].p);
@@ -569,6 +600,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         launch_lap_select(stream_, lay_, i, g_[i].p, i < L ? g_[i + 1].p : nullptr, (const float*)wgt_[i].p,
                           crows >> i, ccols >> i, dtab, tx, by0, by1, bx0, bx1);
         prof_end();
+    }
     }
     HIP_OK(hipGetLastError());
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }

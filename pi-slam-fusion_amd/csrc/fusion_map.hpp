@@ -131,7 +131,7 @@ private:
     TileStore store_;
 
     // per-frame workspace (grow-only)
-    DevBuf g_[kMaxLevels], wgt_[kMaxLevels];
+    DevBuf g_[kMaxLevels], wgt_[kMaxLevels], gw_[kMaxLevels];
     static constexpr int kTableRing = 8;
     uint64_t*  table_host_[kTableRing]{};
     DevBuf     table_dev_[kTableRing];

@@ -286,6 +286,275 @@ void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const vo
     else         hipLaunchKernelGGL(k_lap_select<false>, grid, block, 0, s, lay, level, g_i, g_up, w_i, rows, cols, tile_table, tiles_x, py0, px0, px1, py1);
 }
 
+// ============================================================ fused level
+// k_level: one launch per pyramid level i < L does, for a 64x32 block of level-i
+// pixels, everything that needs G_i:
+//   A  G_i / W_i on the block + halo (4 left/top, 3 right/bottom) into LDS --
+//      level 0: computed by the warp (never written to HBM); level >= 1: read
+//      from the packed GW_i buffer the previous launch wrote
+//   H  horizontal 5-tap decimation of A                      (cv::pyrDown)
+//   B  vertical 5-tap -> G_{i+1} / W_{i+1} on the half-size block + 1 halo;
+//      the block's own part goes to GW_{i+1} (or straight into the top-level
+//      select when i+1 == L)
+//   D  L_i = G_i - pyrUp(G_{i+1}) from LDS, max-weight select into the tiles
+// Out-of-canvas halo entries hold the BORDER_REFLECT_101 pixel, so H/B need
+// no border logic; pyrUp's asymmetric edge rules are applied on global
+// coordinates.  All arithmetic orders are those of the unfused kernels.
+template <bool F32> struct PxT;
+template <> struct alignas(16) PxT<true>  { float c[3]; float w; };
+template <> struct alignas(4)  PxT<false> { short c[3]; short pad; float w; };
+template <bool F32> struct alignas(16) HxT { typename Pix<F32>::WT c[3]; float w; };
+
+constexpr int LBW = 64, LBH = 32, LAW = LBW + 7, LAH = LBH + 7, LQW = LBW / 2 + 2, LQH = LBH / 2 + 2, LNT = 512;
+
+struct LevelArgs {
+    int level, rows, cols;        // level i and its canvas extent
+    int cx0, cy0, cx1, cy1;       // compute region (block grid origin / extent)
+    int tiles_x;
+    int top_select;               // i+1 == L: select the top level from B
+    int write_next;               // i+1 <  L: write GW_{i+1}
+    int nbx, nby;                 // block grid
+};
+
+// one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
+template <bool F32>
+__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const WarpArgs& a, long total, int x, int y)
+{
+    using T = typename Pix<F32>::T;
+    PxT<F32> o;
+    const int xb = x & ~63, x1 = x & 63;                     // OpenCV's 64-wide coordinate block
+    const double X0 = a.M[0] * xb + a.M[1] * y + a.M[2];
+    const double Y0 = a.M[3] * xb + a.M[4] * y + a.M[5];
+    const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
+    const double W  = W0 + a.M[6] * x1;
+    const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
+    const double Wn = W ? 1. / W : 0;
+    const double Wl = Wn * 32.;                              // == 32./W bit for bit (power-of-two scaling)
+    {
+        const int X = __double2int_rn(clamp_int_range(xn * Wn));
+        const int Y = __double2int_rn(clamp_int_range(yn * Wn));
+        const int sx = sat_short(X), sy = sat_short(Y);
+        float wv = 0.f;
+        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
+            const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
+            float dis = dy * dy + dx * dx;
+            dis = 1.f - sqrtf(dis) / a.dis_max;
+            wv = a.weight_type == 0 ? dis : dis * dis;
+            if ((double)wv <= 1e-5) wv = 1e-5f;
+        }
+        o.w = wv;
+    }
+    const int X = __double2int_rn(clamp_int_range(xn * Wl));
+    const int Y = __double2int_rn(clamp_int_range(yn * Wl));
+    const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+    const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
+    int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
+    if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
+        sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
+        sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
+    }
+    // the two taps of a row are the same or adjacent pixels: one unaligned 8-byte load per row
+    const int xbase = sx0 < sx1 ? sx0 : sx1;
+    const int sh0 = (sx0 - xbase) * 24, sh1 = (sx1 - xbase) * 24;
+    uint64_t rowbits[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        long off = (long)(j ? sy1 : sy0) * a.sstep + 3L * xbase;
+        int back = 0;
+        if (off + 8 > total) { back = (int)(off + 8 - total); off -= back; }      // never read past the frame
+        uint64_t v;
+        __builtin_memcpy(&v, src + off, 8);
+        rowbits[j] = v >> (8 * back);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v0 = (float)(uint32_t)((rowbits[0] >> (sh0 + 8 * k)) & 0xff), v1 = (float)(uint32_t)((rowbits[0] >> (sh1 + 8 * k)) & 0xff);
+        float v2 = (float)(uint32_t)((rowbits[1] >> (sh0 + 8 * k)) & 0xff), v3 = (float)(uint32_t)((rowbits[1] >> (sh1 + 8 * k)) & 0xff);
+        if (F32) {
+            const float s = (float)(1. / 255.);
+            v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
+        }
+        const float t = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+        if constexpr (F32) o.c[k] = t;
+        else o.c[k] = (short)sat_short(__float2int_rn(t));
+    }
+    if constexpr (!F32) o.pad = 0;
+    return o;
+}
+
+// horizontal pyrUp term from an LDS row of G_{i+1}; r[X] addresses global column X
+template <bool F32>
+__device__ __forceinline__ typename Pix<F32>::WT up_h_px(const PxT<F32>* __restrict__ r, int k, int x, int scols)
+{
+    using WT = typename Pix<F32>::WT;
+    const int sx = x >> 1;
+    if (scols == 1) return (WT)r[0].c[k] * 8;
+    if (x & 1) {
+        if (sx == scols - 1) return (WT)r[sx].c[k] * 8;
+        return ((WT)r[sx].c[k] + (WT)r[sx + 1].c[k]) * 4;
+    }
+    if (sx == 0) return (WT)r[0].c[k] * 6 + (WT)r[1].c[k] * 2;
+    if (sx == scols - 1) return (WT)r[sx - 1].c[k] + (WT)r[sx].c[k] * 7;
+    return (WT)r[sx - 1].c[k] + (WT)r[sx].c[k] * 6 + (WT)r[sx + 1].c[k];
+}
+
+// max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
+template <bool F32>
+__device__ __forceinline__ void select_store(const TileLayout& lay, int level, const uint64_t* __restrict__ table, int tiles_x,
+                                             int x, int y, const typename Pix<F32>::T v[3], float sw)
+{
+    using T = typename Pix<F32>::T;
+    const int sh = 8 - level, ts = kElePixels >> level;
+    const uint64_t ent = table[(y >> sh) * tiles_x + (x >> sh)];
+    if (!ent) return;
+    char* slot = reinterpret_cast<char*>(ent & ~(uint64_t)1);
+    const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
+    float* dw = reinterpret_cast<float*>(slot + lay.w_off[level]) + loc;
+    if (!(ent & 1) && !(sw >= *dw)) return;
+    T* dl = reinterpret_cast<T*>(slot + lay.lap_off[level]) + loc * 3;
+    dl[0] = v[0]; dl[1] = v[1]; dl[2] = v[2];
+    *dw = sw;
+}
+
+template <bool F32, bool FROM_WARP>
+__global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
+                                                const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
+                                                const uint64_t* __restrict__ table)
+{
+    using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
+    using Px = PxT<F32>; using Hx = HxT<F32>;
+    __shared__ Px A[LAH][LAW];
+    __shared__ Hx Ht[LAH][LQW];
+    __shared__ Px Bt[LQH][LQW];
+
+    // XCD-aware block order: the 8 XCDs take workgroups round-robin, so give each XCD a
+    // contiguous run of blocks (neighbouring blocks share halo pixels in that XCD's L2)
+    const int nblk = g.nbx * g.nby;
+    int b = blockIdx.x;
+    {
+        const int per = nblk >> 3;
+        if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
+    const int bx = b % g.nbx, by = b / g.nbx;
+    const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
+    const int ax0 = x0 - 4, ay0 = y0 - 4;
+    const int nrows = g.rows >> 1, ncols = g.cols >> 1;         // level i+1 extent
+    const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
+    const int tid = threadIdx.x;
+
+    // ---- A
+    const long total = FROM_WARP ? (long)wa.srows * wa.sstep : 0;
+    for (int idx = tid; idx < LAH * LAW; idx += LNT) {
+        const int r = idx / LAW, c = idx - r * LAW;
+        const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
+        if constexpr (FROM_WARP) A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
+        else A[r][c] = gw_in[(long)y * g.cols + x];
+    }
+    __syncthreads();
+    // ---- H
+    for (int idx = tid; idx < LAH * LQW; idx += LNT) {
+        const int r = idx / LQW, q = idx - r * LQW;
+        const Px a0 = A[r][2 * q], a1 = A[r][2 * q + 1], a2 = A[r][2 * q + 2], a3 = A[r][2 * q + 3], a4 = A[r][2 * q + 4];
+        Hx h;
+#pragma unroll
+        for (int k = 0; k < 3; k++) h.c[k] = (WT)a2.c[k] * 6 + ((WT)a1.c[k] + (WT)a3.c[k]) * 4 + (WT)a0.c[k] + (WT)a4.c[k];
+        h.w = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
+        Ht[r][q] = h;
+    }
+    __syncthreads();
+    // ---- B
+    const int vec_img = (ncols * 3 / 8) * 8, vec_w = (ncols / 8) * 8;     // PyrDownVec_32f coverage
+    for (int idx = tid; idx < LQH * LQW; idx += LNT) {
+        const int p = idx / LQW, q = idx - p * LQW;
+        const int Y = by0 + p, X = bx0 + q;
+        if (X < 0 || X >= ncols || Y < 0 || Y >= nrows) continue;
+        const Hx r0 = Ht[2 * p][q], r1 = Ht[2 * p + 1][q], r2 = Ht[2 * p + 2][q], r3 = Ht[2 * p + 3][q], r4 = Ht[2 * p + 4][q];
+        Px o;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if constexpr (F32) {
+                if (X * 3 + k < vec_img) {
+                    float a = r0.c[k] + r4.c[k];
+                    const float bb = (r1.c[k] + r3.c[k]) + r2.c[k];
+                    a = a + (r2.c[k] + r2.c[k]);
+                    o.c[k] = (a + bb * 4.f) * (1.f / 256);
+                } else
+                    o.c[k] = cast_down(r2.c[k] * 6 + (r1.c[k] + r3.c[k]) * 4 + r0.c[k] + r4.c[k]);
+            } else
+                o.c[k] = cast_down(r2.c[k] * 6 + (r1.c[k] + r3.c[k]) * 4 + r0.c[k] + r4.c[k]);
+        }
+        if (X < vec_w) {
+            float a = r0.w + r4.w;
+            const float bb = (r1.w + r3.w) + r2.w;
+            a = a + (r2.w + r2.w);
+            o.w = (a + bb * 4.f) * (1.f / 256);
+        } else
+            o.w = (r2.w * 6 + (r1.w + r3.w) * 4 + r0.w + r4.w) * (1.f / 256);
+        if constexpr (!F32) o.pad = 0;
+        Bt[p][q] = o;
+        if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
+            if (g.write_next) gw_out[(long)Y * ncols + X] = o;
+            if (g.top_select) select_store<F32>(lay, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+        }
+    }
+    __syncthreads();
+    // ---- D
+    for (int idx = tid; idx < LBH * LBW; idx += LNT) {
+        const int ly = idx >> 6, lx = idx & 63;
+        const int y = y0 + ly, x = x0 + lx;
+        if (x >= g.cols || y >= g.rows) continue;
+        const int sh = 8 - g.level, ts = kElePixels >> g.level;
+        const uint64_t ent = table[(y >> sh) * g.tiles_x + (x >> sh)];
+        if (!ent) continue;
+        char* slot = reinterpret_cast<char*>(ent & ~(uint64_t)1);
+        const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
+        float* dw = reinterpret_cast<float*>(slot + lay.w_off[g.level]) + loc;
+        const Px gpx = A[ly + 4][lx + 4];
+        if (!(ent & 1) && !(gpx.w >= *dw)) continue;
+        const int sy = y >> 1;
+        int syn = sy + 1; if (syn >= nrows) syn = nrows - 1;
+        int syp = sy - 1; if (syp < 0) syp = nrows > 1 ? 1 : 0;
+        const Px* r0 = &Bt[syp - by0][0] - bx0;
+        const Px* r1 = &Bt[sy - by0][0] - bx0;
+        const Px* r2 = &Bt[syn - by0][0] - bx0;
+        T* dl = reinterpret_cast<T*>(slot + lay.lap_off[g.level]) + loc * 3;
+        T out[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            T up;
+            if (y & 1) up = cast_up((up_h_px<F32>(r1, k, x, ncols) + up_h_px<F32>(r2, k, x, ncols)) * 4);
+            else up = cast_up(up_h_px<F32>(r0, k, x, ncols) + up_h_px<F32>(r1, k, x, ncols) * 6 + up_h_px<F32>(r2, k, x, ncols));
+            out[k] = sat_sub(gpx.c[k], up);
+        }
+        dl[0] = out[0]; dl[1] = out[1]; dl[2] = out[2];
+        *dw = gpx.w;
+    }
+}
+
+size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
+
+void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
+                  int tiles_x, bool top_select, bool write_next, const WarpArgs* wa, const uint8_t* src,
+                  const void* gw_in, void* gw_out, const uint64_t* table)
+{
+    LevelArgs g{};
+    g.level = level; g.rows = rows; g.cols = cols; g.cx0 = cx0; g.cy0 = cy0; g.cx1 = cx1; g.cy1 = cy1;
+    g.tiles_x = tiles_x; g.top_select = top_select; g.write_next = write_next;
+    g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + LBH - 1) / LBH;
+    if (g.nbx <= 0 || g.nby <= 0) return;
+    dim3 grid(g.nbx * g.nby), block(LNT);
+    WarpArgs w{};
+    if (wa) w = *wa;
+    if (lay.f32) {
+        if (wa) hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, lay, g, w, src, (const PxT<true>*)gw_in, (PxT<true>*)gw_out, table);
+        else    hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, lay, g, w, src, (const PxT<true>*)gw_in, (PxT<true>*)gw_out, table);
+    } else {
+        if (wa) hipLaunchKernelGGL((k_level<false, true>), grid, block, 0, s, lay, g, w, src, (const PxT<false>*)gw_in, (PxT<false>*)gw_out, table);
+        else    hipLaunchKernelGGL((k_level<false, false>), grid, block, 0, s, lay, g, w, src, (const PxT<false>*)gw_in, (PxT<false>*)gw_out, table);
+    }
+}
+
 // ------------------------------------------------------------------ blend
 // strip-set geometry of a neighbour at (dx,dy): level i holds h_i x w_i pixels
 __host__ __device__ inline void strip_dims(int nlev, int level, int dx, int dy, int& w, int& h)
@@ -497,7 +766,7 @@ TileLayout make_layout(int band_num, bool f32)
 const char* kernel_name(int id)
 {
     static const char* n[K_COUNT] = { "warp", "pyrdown_img", "pyrdown_w", "lap_select", "blend_gather", "collapse",
-                                      "blend_finish", "mosaic_gather", "save_finish" };
+                                      "blend_finish", "mosaic_gather", "save_finish", "level0_fused", "level_fused" };
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
 }
 

@@ -48,7 +48,7 @@ struct BlendSrc {
 
 // kernel ids for the profile table
 enum KernelId { K_WARP = 0, K_PYRDOWN_IMG, K_PYRDOWN_W, K_LAP_SELECT, K_BLEND_GATHER, K_COLLAPSE,
-                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_COUNT };
+                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_LEVEL0, K_LEVEL, K_COUNT };
 const char* kernel_name(int id);
 
 void launch_warp(hipStream_t s, bool f32, const uint8_t* src, const WarpArgs& a, void* g0, float* w0);
@@ -63,6 +63,14 @@ void launch_pyrdown(hipStream_t s, int type, const void* src, int srows, int sco
 void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const void* g_i, const void* g_up,
                        const float* w_i, int rows, int cols, const uint64_t* tile_table, int tiles_x,
                        int ty0, int ty1, int tx0, int tx1);
+
+// Fused per-level kernel: level i's Gaussian block (from the warp when
+// wa != nullptr, else from the packed GW_i buffer) -> GW_{i+1} + Laplacian select of level i
+// (+ the top level when top_select).  Compute region [cx0,cx1) x [cy0,cy1) in level-i pixels.
+size_t level_px_bytes(bool f32);
+void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
+                  int tiles_x, bool top_select, bool write_next, const WarpArgs* wa, const uint8_t* src,
+                  const void* gw_in, void* gw_out, const uint64_t* table);
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
 void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,

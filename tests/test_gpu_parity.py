@@ -27,9 +27,10 @@ def run_pair(pf, orc, cam, poses, frames, n_prepare=None, **opt):
     return g, o
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
 @pytest.mark.parametrize("content", ["noise", "smooth"])
-def test_cfg1_plumbing(pf, orc, force_float, content):
+def test_cfg1_plumbing(pf, orc, force_float, content, fused):
     """BASELINE.json configs[0]: 10 synthetic 640x480 frames, identity rotation."""
     wl = workloads()
     cam, poses = wl.cfg1()
@@ -39,16 +40,17 @@ def test_cfg1_plumbing(pf, orc, force_float, content):
     assert compare_maps(g, o) == []
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
-@pytest.mark.parametrize("bands", [1, 3, 5, 7])
-def test_perspective_and_spread(pf, orc, force_float, bands):
+@pytest.mark.parametrize("bands", [0, 1, 3, 5, 7, 8])
+def test_perspective_and_spread(pf, orc, force_float, bands, fused):
     """Rotated / tilted frames; grid prepared from 2 poses so later frames hit spreadMap
     (.cpp:360-379, 561-604); band counts on both sides of the SSE-tail boundary."""
     wl = workloads()
     cam = [640, 480, 500, 500, 320, 240]
     poses = jitter_poses(9, seed=7 + bands)
     frames = [wl.noise_frame(480, 640, 100 + k) for k in range(len(poses))]
-    g, o = run_pair(pf, orc, cam, poses, frames, n_prepare=2, force_float=force_float, band_number=bands)
+    g, o = run_pair(pf, orc, cam, poses, frames, n_prepare=2, force_float=force_float, band_number=bands, fused=fused)
     assert compare_maps(g, o) == []
 
 
@@ -175,13 +177,14 @@ def test_device_resident_feed_and_idempotence(pf):
     assert map_digest(a) == da
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
-def test_full_size_frame_against_oracle(pf, orc, force_float):
+def test_full_size_frame_against_oracle(pf, orc, force_float, fused):
     """BASELINE.json configs[1] geometry: one 4000x3000 frame, 5 bands, vs the oracle (seconds on CPU)."""
     wl = workloads()
     cam, poses = wl.cfg2(3)
     frame = wl.noise_frame(3000, 4000, 9)
-    g, o = run_pair(pf, orc, cam, poses[:1], [frame], force_float=force_float)
+    g, o = run_pair(pf, orc, cam, poses[:1], [frame], force_float=force_float, fused=fused)
     assert len(o.tiles()) >= 200
     assert compare_maps(g, o) == []
 

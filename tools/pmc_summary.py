@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output for profiles/.
+
+  kernel stats : tools/pmc_summary.py stats <dir with *_kernel_stats.csv> > profiles/<name>.md
+  HBM traffic  : tools/pmc_summary.py traffic <fetch dir> <write dir> <dtype> [profiles/pmc_traffic.json]
+
+Traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes; both are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
+wide coalesced read, so it is doubled; WRITE_SIZE is taken as is.  Per launch = mean over
+the launches of that kernel in the pass (same mix of pyramid levels as bench.py's
+per-launch `achieved`)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_pyrdown", "pyrdown_img"),
+         ("k_lap_select", "lap_select"), ("k_level", "level"), ("k_blend_gather", "blend_gather"), ("k_collapse", "collapse"),
+         ("k_blend_finish", "blend_finish"), ("k_mosaic_gather", "mosaic_gather"), ("k_save_finish", "save_finish")]
+
+
+def short(name):
+    for k, s in SHORT:
+        if k in name:
+            return s
+    return None
+
+
+def find(d, pat):
+    f = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    if not f:
+        raise SystemExit("no %s under %s" % (pat, d))
+    return f[0]
+
+
+def stats(d):
+    rows = list(csv.DictReader(open(find(d, "*_kernel_stats.csv"))))
+    print("| kernel | calls | total ms | avg us | min us | max us | % |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows:
+        n = re.sub(r"\(.*", "", r["Name"])[:70]
+        print("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (n, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+              float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+
+
+def counter_means(d, counter):
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+        if r["Counter_Name"] != counter:
+            continue
+        s = short(r["Kernel_Name"])
+        if s:
+            acc[s].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+def traffic(fd, wd, dtype, out):
+    f, nf = counter_means(fd, "FETCH_SIZE")
+    w, _ = counter_means(wd, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        res[k] = int(round(2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024))
+        print("%-14s launches %5d  fetch(x2) %10.1f KiB  write %10.1f KiB  -> %d B/launch" %
+              (k, nf.get(k, 0), 2 * f.get(k, 0.0), w.get(k, 0.0), res[k]), file=sys.stderr)
+    if out:
+        cur = json.load(open(out)) if os.path.exists(out) else {}
+        cur[dtype] = res
+        json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
