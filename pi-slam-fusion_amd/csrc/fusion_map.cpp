@@ -112,10 +112,15 @@ FusionMap::~FusionMap()
     }
     if (!init_ok_) return;
     (void)hipSetDevice(device_);
-    (void)hipStreamSynchronize(stream_);
+    (void)sync_all();
     (void)hipStreamSynchronize(copy_stream_);
     prof_harvest();
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    for (int i = 0; i < kMaxLevels; i++) {
+        if (i > 0 && lvl_stream_[i]) (void)hipStreamDestroy(lvl_stream_[i]);
+        for (int k = 0; k < kTableRing; k++) if (lvl_ev_[i][k]) (void)hipEventDestroy(lvl_ev_[i][k]);
+        gw_[i].release(); gw2_[i].release();
+    }
     for (auto& s : slots_) { if (s.dev) (void)hipFree(s.dev); if (s.consumed) (void)hipEventDestroy(s.consumed); }
     for (int i = 0; i < kTableRing; i++) {
         if (table_host_[i]) (void)hipHostFree(table_host_[i]);
@@ -131,24 +136,35 @@ FusionMap::~FusionMap()
 
 bool FusionMap::set_device() { HIP_OK(hipSetDevice(device_)); return true; }
 
+// every stream this map launches on: the main stream (level 0, blend, save) and the
+// per-level streams of the fused pipeline
+hipError_t FusionMap::sync_all()
+{
+    hipError_t e = hipStreamSynchronize(stream_);
+    for (int i = 1; i < kMaxLevels; i++)
+        if (lvl_stream_[i]) { hipError_t e2 = hipStreamSynchronize(lvl_stream_[i]); if (e == hipSuccess) e = e2; }
+    return e;
+}
+
 // ---------------------------------------------------------------- profile
 void FusionMap::profile_enable(int mode) { std::lock_guard<std::mutex> l(mu_); prof_mode_ = mode; }
 
-void FusionMap::prof_begin(int id, double bytes)
+void FusionMap::prof_begin(int id, double bytes, hipStream_t st)
 {
+    prof_stream_ = st ? st : stream_;
     prof_on_ = prof_mode_ == 1 || prof_mode_ == 2 + id;      // mode 2+k: only kernel k
     if (!prof_on_) return;
     auto get = [&]() { hipEvent_t e; if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); } else (void)hipEventCreate(&e); return e; };
     prof_cur_ = { id, get(), get(), bytes };
-    (void)hipEventRecord(prof_cur_.a, stream_);
+    (void)hipEventRecord(prof_cur_.a, prof_stream_);
 }
 
 void FusionMap::prof_end()
 {
     if (!prof_on_) return;
-    (void)hipEventRecord(prof_cur_.b, stream_);
+    (void)hipEventRecord(prof_cur_.b, prof_stream_);
     prof_pending_.push_back(prof_cur_);
-    if (prof_pending_.size() > 4096) { (void)hipStreamSynchronize(stream_); prof_harvest(); }
+    if (prof_pending_.size() > 4096) { (void)sync_all(); prof_harvest(); }
 }
 
 void FusionMap::prof_harvest()
@@ -165,7 +181,7 @@ int FusionMap::profile_read(int cap, const char** names, double* ms, long long* 
 {
     std::lock_guard<std::mutex> l(mu_);
     (void)hipSetDevice(device_);
-    (void)hipStreamSynchronize(stream_);
+    (void)sync_all();
     prof_harvest();
     int n = 0;
     for (int i = 0; i < K_COUNT && n < cap; i++, n++) {
@@ -178,7 +194,7 @@ void FusionMap::profile_reset()
 {
     std::lock_guard<std::mutex> l(mu_);
     (void)hipSetDevice(device_);
-    (void)hipStreamSynchronize(stream_);
+    (void)sync_all();
     prof_harvest();
     for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; }
 }
@@ -244,7 +260,7 @@ bool FusionMap::prepare(const double plane7[7], const double cam[6], int n, cons
     }
     std::lock_guard<std::mutex> l(mu_);
     if (!set_device()) return false;
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     store_.clear();
     plane_ = plane; plane_inv_ = pinv; cam_ = c;
     length_pixel_ = length_pixel; length_pixel_inv_ = 1. / length_pixel;
@@ -396,7 +412,7 @@ bool FusionMap::sync()
     }
     std::lock_guard<std::mutex> l(mu_);
     if (!set_device()) return false;
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     prof_harvest();
     return true;
 }
@@ -497,15 +513,15 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     bool grow = false;
     for (int i = 0; i <= L; i++) {
         const size_t n = (size_t)(crows >> i) * (ccols >> i);
-        if (fused) { if (i >= 1 && i < L && gw_[i].cap < n * pxb) grow = true; }
+        if (fused) { if (i >= 1 && i < L && (gw_[i].cap < n * pxb || gw2_[i].cap < n * pxb)) grow = true; }
         else if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
     }
     if (table_cap_ < (size_t)tx * ty) grow = true;
     if (grow) {
-        HIP_OK(hipStreamSynchronize(stream_));
+        HIP_OK(sync_all());
         for (int i = 0; i <= L; i++) {
             const size_t n = (size_t)(crows >> i) * (ccols >> i);
-            if (fused) { if (i >= 1 && i < L && !gw_[i].reserve(n * pxb)) return false; }
+            if (fused) { if (i >= 1 && i < L && (!gw_[i].reserve(n * pxb) || !gw2_[i].reserve(n * pxb))) return false; }
             else if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
         }
         if (table_cap_ < (size_t)tx * ty) {
@@ -564,18 +580,39 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             clampw(x0, x1, cols, C[i].x0, C[i].x1);
             clampw(y0, y1, rows, C[i].y0, C[i].y1);
         }
+        // One stream per level: level i of frame f runs after level i-1 of frame f (GW_i) and, by
+        // stream order, after level i of frame f-1 (tiles are updated in feed order).  The small
+        // upper levels of frame f thus overlap the level-0 kernel of frame f+1.  GW buffers are
+        // double-buffered by frame parity; a writer waits for the reader two frames back.
         const double E = 3 * es + 4;
+        const unsigned long long fidx = frame_seq_ - 1;
+        const int slot = (int)(fidx % kTableRing);
+        DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
         for (int i = 0; i < L; i++) {
+            if (!lvl_stream_[i]) {
+                if (i == 0) lvl_stream_[0] = stream_;
+                else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
+            }
+            for (int k = 0; k < kTableRing; k++)
+                if (!lvl_ev_[i][k]) HIP_OK(hipEventCreateWithFlags(&lvl_ev_[i][k], hipEventDisableTiming));
+        }
+        for (int i = 0; i < L; i++) {
+            hipStream_t st = lvl_stream_[i];
             const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
             const bool top = (i + 1 == L);
+            if (i > 0) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i - 1][slot], 0));
+            if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kTableRing)], 0));
             // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
             double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
             if (i == 0) bytes += 3.0 * f.rows * f.cols;
-            prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes);
-            launch_level(stream_, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
-                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw_[i].p, top ? nullptr : gw_[i + 1].p, dtab);
+            prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
+            launch_level(st, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
+                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab);
             prof_end();
+            HIP_OK(hipEventRecord(lvl_ev_[i][slot], st));
         }
+        // the tile table of this ring slot is read until the last level has run
+        HIP_OK(hipEventRecord(table_ev_[ring], lvl_stream_[L - 1]));
     } else {
     const double win0 = (double)a.wrows * a.wcols;
     prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
@@ -643,7 +680,7 @@ bool FusionMap::get_tile_level(int ix, int iy, int level, void* lap, float* w)
     if (!init_ok_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh || level < 0 || level > band_num_) return false;
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     const size_t n = (size_t)(kElePixels >> level) * (kElePixels >> level);
     if (lap) HIP_OK(hipMemcpy(lap, t->base + lay_.lap_off[level], n * 3 * (lay_.f32 ? 4 : 2), hipMemcpyDeviceToHost));
     if (w) HIP_OK(hipMemcpy(w, t->base + lay_.w_off[level], n * 4, hipMemcpyDeviceToHost));
@@ -657,7 +694,7 @@ bool FusionMap::halo_pack(int ix, int iy, int dx, int dy, void* dev_out)
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
     launch_halo_pack(stream_, lay_, t->base, dx, dy, dev_out);
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     return true;
 }
 
@@ -668,7 +705,7 @@ bool FusionMap::tile_export(int ix, int iy, void* dev_out)
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
     HIP_OK(hipMemcpyAsync(dev_out, t->base, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     return true;
 }
 
@@ -679,7 +716,7 @@ bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
     Tile* t = store_.get_or_create(ix, iy);
     if (!t) return false;
     HIP_OK(hipMemcpyAsync(t->base, dev_in, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     t->fresh = false; t->changed = true;
     return true;
 }
@@ -744,7 +781,7 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
         launch_blend_finish(stream_, lay_, blend_lv_[0].p, stride[0], b0, dsrc, raw_host ? blend_out_raw_.p : nullptr,
                             bgr_host ? (uint8_t*)blend_out_bgr_.p : nullptr, batch);
         prof_end();
-        HIP_OK(hipStreamSynchronize(stream_));
+        HIP_OK(sync_all());
         for (int k = 0; k < batch; k++) {
             if (raw_host) HIP_OK(hipMemcpy((char*)raw_host + (size_t)idx[k] * tile_px * px, (char*)blend_out_raw_.p + (size_t)k * tile_px * px, tile_px * px, hipMemcpyDeviceToHost));
             if (bgr_host) HIP_OK(hipMemcpy(bgr_host + (size_t)idx[k] * tile_px * 3, (char*)blend_out_bgr_.p + (size_t)k * tile_px * 3, tile_px * 3, hipMemcpyDeviceToHost));
@@ -809,7 +846,7 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     std::vector<uint64_t> tab((size_t)wx * wy, 0);
     store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) tab[(size_t)(iy - mny) * wx + (ix - mnx)] = (uint64_t)(uintptr_t)t.base; });
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     if (!mosaic_table_.reserve(tab.size() * 8)) return false;
     HIP_OK(hipMemcpy(mosaic_table_.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     for (int i = 0; i <= L; i++) {
@@ -829,7 +866,7 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     prof_begin(K_SAVE_FINISH, (double)*rows * *cols * (px + 4 + 3));
     launch_save_finish(stream_, lay_, blend_lv_[0].p, (const uint64_t*)mosaic_table_.p, wx, wy, opt_.bg_color, (uint8_t*)blend_out_bgr_.p);
     prof_end();
-    HIP_OK(hipStreamSynchronize(stream_));
+    HIP_OK(sync_all());
     HIP_OK(hipMemcpy(bgr, blend_out_bgr_.p, out_bytes, hipMemcpyDeviceToHost));
     return true;
 }

@@ -108,7 +108,8 @@ private:
     int  acquire_slot(size_t bytes);
     bool upload(const pf_image* img, int slot);
     bool blend_batch(const std::vector<std::pair<int,int>>& tiles, const void* const* halo, void* raw_host, uint8_t* bgr_host);
-    void prof_begin(int id, double bytes);
+    void prof_begin(int id, double bytes, hipStream_t st = nullptr);
+    hipError_t sync_all();
     void prof_end();
     void prof_harvest();
     bool set_device();
@@ -131,7 +132,10 @@ private:
     TileStore store_;
 
     // per-frame workspace (grow-only)
-    DevBuf g_[kMaxLevels], wgt_[kMaxLevels], gw_[kMaxLevels];
+    DevBuf g_[kMaxLevels], wgt_[kMaxLevels], gw_[kMaxLevels], gw2_[kMaxLevels];
+    hipStream_t lvl_stream_[kMaxLevels]{};          // fused pipeline: one stream per level ([0] aliases stream_)
+    hipEvent_t  lvl_ev_[kMaxLevels][8]{};           // level i of the frame in ring slot k has run
+    hipStream_t prof_stream_ = nullptr;
     static constexpr int kTableRing = 8;
     uint64_t*  table_host_[kTableRing]{};
     DevBuf     table_dev_[kTableRing];

@@ -14,6 +14,7 @@
 //   k_mosaic_gather / k_save_finish  :806-840 save
 #include "kernels.hpp"
 #include <climits>
+#include <cstdlib>
 
 namespace pf {
 
@@ -43,6 +44,10 @@ __device__ __forceinline__ double clamp_int_range(double v)
     v = ((double)INT_MIN < v) ? v : (double)INT_MIN;     // std::max((double)INT_MIN, v)
     return v;
 }
+
+// tile slots are reached through integers of the tile table: tell the compiler they are global
+// memory, otherwise every tile access becomes a FLAT instruction
+#define PF_GLOBAL __attribute__((address_space(1)))
 
 template <bool F32> struct Pix;
 template <> struct Pix<false> { using T = short; using WT = int;   static constexpr int bytes = 2; };
@@ -314,6 +319,7 @@ struct LevelArgs {
     int top_select;               // i+1 == L: select the top level from B
     int write_next;               // i+1 <  L: write GW_{i+1}
     int nbx, nby;                 // block grid
+    int ablate;                   // diagnostics only (PF_ABLATE): bit0 skip A math, bit1 skip H/B, bit2 skip U/D
 };
 
 // one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
@@ -329,48 +335,71 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     const double W  = W0 + a.M[6] * x1;
     const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
     const double Wn = W ? 1. / W : 0;
-    const double Wl = Wn * 32.;                              // == 32./W bit for bit (power-of-two scaling)
+    // nearest coordinate p = (X0+M0*x1)*(1/W); the 1/32-px coordinate (X0+M0*x1)*(32/W) equals 32*p
+    // bit for bit (32/W == 32*(1/W) and scaling by a power of two commutes with rounding).
+    // v_cvt_i32_f64 saturates, which is exactly clamp-to-int-range followed by cvRound.
+    const double pxn = xn * Wn, pyn = yn * Wn;
     {
-        const int X = __double2int_rn(clamp_int_range(xn * Wn));
-        const int Y = __double2int_rn(clamp_int_range(yn * Wn));
-        const int sx = sat_short(X), sy = sat_short(Y);
+        const int sx = sat_short(__double2int_rn(pxn)), sy = sat_short(__double2int_rn(pyn));
         float wv = 0.f;
         if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
             const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
             float dis = dy * dy + dx * dx;
             dis = 1.f - sqrtf(dis) / a.dis_max;
             wv = a.weight_type == 0 ? dis : dis * dis;
-            if ((double)wv <= 1e-5) wv = 1e-5f;
+            if (wv <= 1e-5f) wv = 1e-5f;          // == ((double)wv <= 1e-5): 1e-5f is the largest float below 1e-5
         }
         o.w = wv;
     }
-    const int X = __double2int_rn(clamp_int_range(xn * Wl));
-    const int Y = __double2int_rn(clamp_int_range(yn * Wl));
+    const int X = __double2int_rn(pxn * 32.);
+    const int Y = __double2int_rn(pyn * 32.);
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
     const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
-    int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
-    if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
-        sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
-        sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
-    }
-    // the two taps of a row are the same or adjacent pixels: one unaligned 8-byte load per row
-    const int xbase = sx0 < sx1 ? sx0 : sx1;
-    const int sh0 = (sx0 - xbase) * 24, sh1 = (sx1 - xbase) * 24;
-    uint64_t rowbits[2];
+    float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
+    // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes 3..5
+    const long off0 = (long)sy * a.sstep + 3L * sx;
+    const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1) &&
+                      off0 + a.sstep + 8 <= total;
+    if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
+        // whole wave strictly inside the frame: no border mapping, taps are (lo, hi) of each row
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        long off = (long)(j ? sy1 : sy0) * a.sstep + 3L * xbase;
-        int back = 0;
-        if (off + 8 > total) { back = (int)(off + 8 - total); off -= back; }      // never read past the frame
-        uint64_t v;
-        __builtin_memcpy(&v, src + off, 8);
-        rowbits[j] = v >> (8 * back);
+        for (int j = 0; j < 2; j++) {
+            uint64_t bits;
+            __builtin_memcpy(&bits, src + off0 + (j ? a.sstep : 0), 8);
+            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
+            v[2 * j + 1][0] = (float)(lo >> 24); v[2 * j + 1][1] = (float)(hi & 0xff); v[2 * j + 1][2] = (float)((hi >> 8) & 0xff);
+        }
+    } else {
+        int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
+        if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
+            sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
+            sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
+        }
+        // after BORDER_REFLECT the two taps of a row are the same or adjacent pixels
+        const int xbase = sx0 < sx1 ? sx0 : sx1;
+        const bool t0hi = sx0 != xbase, t1hi = sx1 != xbase;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const long off = (long)(j ? sy1 : sy0) * a.sstep + 3L * xbase;
+            uint64_t bits;
+            if (off + 8 > total) {           // last bytes of the frame: never read past it
+                const int back = (int)(off + 8 - total);
+                __builtin_memcpy(&bits, src + (off - back), 8);
+                bits >>= 8 * back;
+            } else
+                __builtin_memcpy(&bits, src + off, 8);
+            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            const float l0 = (float)(lo & 0xff), l1 = (float)((lo >> 8) & 0xff), l2 = (float)((lo >> 16) & 0xff);
+            const float h0 = (float)(lo >> 24), h1 = (float)(hi & 0xff), h2 = (float)((hi >> 8) & 0xff);
+            v[2 * j][0] = t0hi ? h0 : l0; v[2 * j][1] = t0hi ? h1 : l1; v[2 * j][2] = t0hi ? h2 : l2;
+            v[2 * j + 1][0] = t1hi ? h0 : l0; v[2 * j + 1][1] = t1hi ? h1 : l1; v[2 * j + 1][2] = t1hi ? h2 : l2;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float v0 = (float)(uint32_t)((rowbits[0] >> (sh0 + 8 * k)) & 0xff), v1 = (float)(uint32_t)((rowbits[0] >> (sh1 + 8 * k)) & 0xff);
-        float v2 = (float)(uint32_t)((rowbits[1] >> (sh0 + 8 * k)) & 0xff), v3 = (float)(uint32_t)((rowbits[1] >> (sh1 + 8 * k)) & 0xff);
+        float v0 = v[0][k], v1 = v[1][k], v2 = v[2][k], v3 = v[3][k];
         if (F32) {
             const float s = (float)(1. / 255.);
             v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
@@ -383,20 +412,25 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     return o;
 }
 
-// horizontal pyrUp term from an LDS row of G_{i+1}; r[X] addresses global column X
-template <bool F32>
-__device__ __forceinline__ typename Pix<F32>::WT up_h_px(const PxT<F32>* __restrict__ r, int k, int x, int scols)
+// horizontal pyrUp term of one G_{i+1} row (pyramids.cpp pyrUp_): a,b,c = s[sx-1], s[sx], s[sx+1].
+// EDGE = the block touches the canvas' left/right edge, where the fp32 forms differ from the
+// interior ones (s[0]*6+s[1]*2, s[n-2]+s[n-1]*7, s[n-1]*8); for int16 they are the same integers
+// as the interior form on reflected/replicated indices, which the caller supplies.
+template <typename WT, bool EDGE>
+__device__ __forceinline__ WT up_h_val(WT a, WT b, WT c, bool odd, bool le, bool re, bool one)
 {
-    using WT = typename Pix<F32>::WT;
-    const int sx = x >> 1;
-    if (scols == 1) return (WT)r[0].c[k] * 8;
-    if (x & 1) {
-        if (sx == scols - 1) return (WT)r[sx].c[k] * 8;
-        return ((WT)r[sx].c[k] + (WT)r[sx + 1].c[k]) * 4;
+    if (odd) {
+        WT t = (b + c) * 4;
+        if (EDGE) { if (re || one) t = b * 8; }
+        return t;
     }
-    if (sx == 0) return (WT)r[0].c[k] * 6 + (WT)r[1].c[k] * 2;
-    if (sx == scols - 1) return (WT)r[sx - 1].c[k] + (WT)r[sx].c[k] * 7;
-    return (WT)r[sx - 1].c[k] + (WT)r[sx].c[k] * 6 + (WT)r[sx + 1].c[k];
+    WT t = a + b * 6 + c;
+    if (EDGE) {
+        if (le) t = b * 6 + c * 2;
+        if (re) t = a + b * 7;
+        if (one) t = b * 8;
+    }
+    return t;
 }
 
 // max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
@@ -408,14 +442,18 @@ __device__ __forceinline__ void select_store(const TileLayout& lay, int level, c
     const int sh = 8 - level, ts = kElePixels >> level;
     const uint64_t ent = table[(y >> sh) * tiles_x + (x >> sh)];
     if (!ent) return;
-    char* slot = reinterpret_cast<char*>(ent & ~(uint64_t)1);
+    const uint64_t slot = ent & ~(uint64_t)1;
     const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
-    float* dw = reinterpret_cast<float*>(slot + lay.w_off[level]) + loc;
+    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off[level]) + loc;
     if (!(ent & 1) && !(sw >= *dw)) return;
-    T* dl = reinterpret_cast<T*>(slot + lay.lap_off[level]) + loc * 3;
+    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[level]) + loc * 3;
     dl[0] = v[0]; dl[1] = v[1]; dl[2] = v[2];
     *dw = sw;
 }
+
+// workgroup barrier that waits for this wave's LDS traffic only: global loads issued earlier
+// (the D-stage weight prefetch) stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <bool F32, bool FROM_WARP>
 __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
@@ -443,15 +481,66 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
     const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
     const int tid = threadIdx.x;
 
+    // tile-table entries of this thread's D pixels: loaded now, used after stage A
+    constexpr int ND = LBH * LBW / LNT;
+    const int sh = 8 - g.level, ts = kElePixels >> g.level;
+    uint64_t ents[ND];
+    float dwv[ND];
+#pragma unroll
+    for (int it = 0; it < ND; it++) {
+        const int idx = tid + it * LNT, y = y0 + (idx >> 6), x = x0 + (idx & 63);
+        ents[it] = (x < g.cols && y < g.rows) ? table[(y >> sh) * g.tiles_x + (x >> sh)] : 0;
+    }
+
     // ---- A
     const long total = FROM_WARP ? (long)wa.srows * wa.sstep : 0;
-    for (int idx = tid; idx < LAH * LAW; idx += LNT) {
-        const int r = idx / LAW, c = idx - r * LAW;
-        const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
-        if constexpr (FROM_WARP) A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
-        else A[r][c] = gw_in[(long)y * g.cols + x];
+    if constexpr (FROM_WARP) {
+        // blocks whose halo lies inside the canvas (all but the rim) skip the REFLECT_101 mapping
+        const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
+        int r = tid / LAW, c = tid - r * LAW;
+        for (int idx = tid; idx < LAH * LAW; idx += LNT) {
+            int y = ay0 + r, x = ax0 + c;
+            if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
+            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; } else
+            A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
+            c += LNT % LAW; r += LNT / LAW;
+            if (c >= LAW) { c -= LAW; r++; }
+        }
+    } else {
+        // all of a thread's loads are issued before the first LDS store
+        constexpr int NIT = (LAH * LAW + LNT - 1) / LNT;
+        Px tmp[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * LNT;
+            if (idx < LAH * LAW) {
+                const int r = idx / LAW, c = idx - r * LAW;
+                const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
+                tmp[it] = gw_in[(long)y * g.cols + x];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * LNT;
+            if (idx < LAH * LAW) { const int r = idx / LAW, c = idx - r * LAW; A[r][c] = tmp[it]; }
+        }
     }
-    __syncthreads();
+    lds_barrier();
+    if (g.ablate & 2) return;
+    // stored weights of the D pixels: in flight during H / B / U (the barriers below wait for LDS only)
+#pragma unroll
+    for (int it = 0; it < ND; it++) {
+        uint64_t ent = ents[it];
+        if (ts >= LBW)        // a 64-pixel row segment lies in one tile: make the slot address wave-uniform
+            ent = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ent >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ent);
+        ents[it] = ent;
+        dwv[it] = -1.f;                                   // fresh tile: every weight (>= 0) wins
+        if (ent && !(ent & 1)) {
+            const int idx = tid + it * LNT, y = y0 + (idx >> 6), x = x0 + (idx & 63);
+            dwv[it] = ((const float PF_GLOBAL*)((ent & ~(uint64_t)1) + lay.w_off[g.level]))[(y & (ts - 1)) * ts + (x & (ts - 1))];
+        }
+    }
     // ---- H
     for (int idx = tid; idx < LAH * LQW; idx += LNT) {
         const int r = idx / LQW, q = idx - r * LQW;
@@ -462,7 +551,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         h.w = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
         Ht[r][q] = h;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- B
     const int vec_img = (ncols * 3 / 8) * 8, vec_w = (ncols / 8) * 8;     // PyrDownVec_32f coverage
     for (int idx = tid; idx < LQH * LQW; idx += LNT) {
@@ -498,37 +587,61 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
             if (g.top_select) select_store<F32>(lay, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
         }
     }
-    __syncthreads();
-    // ---- D
-    for (int idx = tid; idx < LBH * LBW; idx += LNT) {
-        const int ly = idx >> 6, lx = idx & 63;
-        const int y = y0 + ly, x = x0 + lx;
-        if (x >= g.cols || y >= g.rows) continue;
-        const int sh = 8 - g.level, ts = kElePixels >> g.level;
-        const uint64_t ent = table[(y >> sh) * g.tiles_x + (x >> sh)];
+    lds_barrier();
+    if (g.ablate & 4) return;
+    // ---- U: horizontal pyrUp of the B rows into LDS (re-uses Ht, dead after B)
+    Hx (*U)[LBW] = reinterpret_cast<Hx (*)[LBW]>(&Ht[0][0]);
+    static_assert(sizeof(Hx) * LQH * LBW <= sizeof(Hx) * LAH * LQW, "U must fit in Ht");
+    const bool edge = (x0 == 0) || (x0 + LBW >= g.cols) || (ncols == 1);
+    for (int idx = tid; idx < LQH * LBW; idx += LNT) {
+        const int p = idx >> 6, lx = idx & 63;
+        const int x = x0 + lx, sx = x >> 1, j = (lx >> 1) + 1;
+        Hx u;
+        if (!edge) {
+            const Px a = Bt[p][j - 1], b = Bt[p][j], c = Bt[p][j + 1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) u.c[k] = up_h_val<WT, false>((WT)a.c[k], (WT)b.c[k], (WT)c.c[k], x & 1, false, false, false);
+        } else {
+            const bool one = ncols == 1, le = sx == 0, re = sx == ncols - 1;
+            // int16: reflected (left) / replicated (right) neighbours; fp32: values unused where le/re select
+            const Px a = Bt[p][(le && !F32) ? (one ? j : j + 1) : j - 1], b = Bt[p][j], c = Bt[p][(re && !F32) ? j : j + 1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if constexpr (F32) u.c[k] = up_h_val<WT, true>(a.c[k], b.c[k], c.c[k], x & 1, le, re, one);
+                else u.c[k] = up_h_val<WT, false>((WT)a.c[k], (WT)b.c[k], (WT)c.c[k], x & 1, false, false, false);
+            }
+        }
+        u.w = 0.f;
+        U[p][lx] = u;
+    }
+    lds_barrier();
+    // ---- D: vertical pyrUp, Laplacian, max-weight select (one wave = one 64-pixel row)
+#pragma unroll
+    for (int it = 0; it < ND; it++) {
+        const uint64_t ent = ents[it];
         if (!ent) continue;
-        char* slot = reinterpret_cast<char*>(ent & ~(uint64_t)1);
-        const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
-        float* dw = reinterpret_cast<float*>(slot + lay.w_off[g.level]) + loc;
+        const int idx = tid + it * LNT, ly = idx >> 6, lx = idx & 63;
+        const int y = y0 + ly, x = x0 + lx;
         const Px gpx = A[ly + 4][lx + 4];
-        if (!(ent & 1) && !(gpx.w >= *dw)) continue;
+        if (!(gpx.w >= dwv[it])) continue;
+        const uint64_t slot = ent & ~(uint64_t)1;
+        const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
         const int sy = y >> 1;
         int syn = sy + 1; if (syn >= nrows) syn = nrows - 1;
         int syp = sy - 1; if (syp < 0) syp = nrows > 1 ? 1 : 0;
-        const Px* r0 = &Bt[syp - by0][0] - bx0;
-        const Px* r1 = &Bt[sy - by0][0] - bx0;
-        const Px* r2 = &Bt[syn - by0][0] - bx0;
-        T* dl = reinterpret_cast<T*>(slot + lay.lap_off[g.level]) + loc * 3;
+        const Hx u1 = U[sy - by0][lx], u2 = U[syn - by0][lx];
         T out[3];
+        if (y & 1) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            T up;
-            if (y & 1) up = cast_up((up_h_px<F32>(r1, k, x, ncols) + up_h_px<F32>(r2, k, x, ncols)) * 4);
-            else up = cast_up(up_h_px<F32>(r0, k, x, ncols) + up_h_px<F32>(r1, k, x, ncols) * 6 + up_h_px<F32>(r2, k, x, ncols));
-            out[k] = sat_sub(gpx.c[k], up);
+            for (int k = 0; k < 3; k++) out[k] = sat_sub(gpx.c[k], cast_up((u1.c[k] + u2.c[k]) * 4));
+        } else {
+            const Hx u0 = U[syp - by0][lx];
+#pragma unroll
+            for (int k = 0; k < 3; k++) out[k] = sat_sub(gpx.c[k], cast_up(u0.c[k] + u1.c[k] * 6 + u2.c[k]));
         }
+        T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[g.level]) + loc * 3;
         dl[0] = out[0]; dl[1] = out[1]; dl[2] = out[2];
-        *dw = gpx.w;
+        ((float PF_GLOBAL*)(slot + lay.w_off[g.level]))[loc] = gpx.w;
     }
 }
 
@@ -542,6 +655,8 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     g.level = level; g.rows = rows; g.cols = cols; g.cx0 = cx0; g.cy0 = cy0; g.cx1 = cx1; g.cy1 = cy1;
     g.tiles_x = tiles_x; g.top_select = top_select; g.write_next = write_next;
     g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + LBH - 1) / LBH;
+    static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
+    g.ablate = ablate;
     if (g.nbx <= 0 || g.nby <= 0) return;
     dim3 grid(g.nbx * g.nby), block(LNT);
     WarpArgs w{};
