@@ -117,7 +117,7 @@ FusionMap::~FusionMap()
     prof_harvest();
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
     for (int i = 0; i < kMaxLevels; i++) {
-        if (i > 0 && lvl_stream_[i]) (void)hipStreamDestroy(lvl_stream_[i]);
+        if (i > 0 && lvl_stream_[i] && lvl_stream_[i] != stream_) (void)hipStreamDestroy(lvl_stream_[i]);
         for (int k = 0; k < kTableRing; k++) if (lvl_ev_[i][k]) (void)hipEventDestroy(lvl_ev_[i][k]);
         gw_[i].release(); gw2_[i].release();
     }
@@ -142,7 +142,7 @@ hipError_t FusionMap::sync_all()
 {
     hipError_t e = hipStreamSynchronize(stream_);
     for (int i = 1; i < kMaxLevels; i++)
-        if (lvl_stream_[i]) { hipError_t e2 = hipStreamSynchronize(lvl_stream_[i]); if (e == hipSuccess) e = e2; }
+        if (lvl_stream_[i] && lvl_stream_[i] != stream_) { hipError_t e2 = hipStreamSynchronize(lvl_stream_[i]); if (e == hipSuccess) e = e2; }
     return e;
 }
 
@@ -591,6 +591,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         for (int i = 0; i < L; i++) {
             if (!lvl_stream_[i]) {
                 if (i == 0) lvl_stream_[0] = stream_;
+                else if (std::getenv("PF_SINGLE_STREAM")) lvl_stream_[i] = stream_;      // diagnostics: serial kernel times
                 else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
             }
             for (int k = 0; k < kTableRing; k++)

@@ -1,0 +1,86 @@
+"""Tile sharding on the GPU: two shard maps on one card, each fed every keyframe,
+against the unsharded map.  feed() uses no collective: a shard renders the sub-canvas of its
+owned tiles plus the pyramid halo, so the union of the shards' tiles must equal the unsharded
+tiles bit for bit; blend() with packed halo strips and save() after the tile gather too."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import jitter_poses, map_digest, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def build(pf, cam, poses, frames, n, block, force_float, fused=1, **kw):
+    wl = workloads()
+    maps = []
+    for r in range(n):
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, shard_rank=r, shard_count=n,
+                            shard_block=block, fused=fused, **kw)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+        for f, p in zip(frames, poses):
+            assert m.feed(f, p)
+        m.sync()
+        maps.append(m)
+    return maps
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("force_float", [0, 1])
+@pytest.mark.parametrize("block", [1, 2])
+def test_shards_union_equals_unsharded(pf, force_float, block, fused):
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(8, seed=31, step=(22.0, 17.0))
+    frames = [wl.noise_frame(480, 640, 500 + k) for k in range(len(poses))]
+    (ref,) = build(pf, cam, poses, frames, 1, 1, force_float, fused)
+    shards = build(pf, cam, poses, frames, 2, block, force_float, fused)
+    dref = map_digest(ref)
+    got = {}
+    for r, m in enumerate(shards):
+        for (ix, iy) in m.tiles():
+            assert pf.tile_owner(m.opt, ix, iy) == r
+        d = map_digest(m)
+        assert not (set(d) & set(got))
+        got.update(d)
+    assert all(len(m.tiles()) > 0 for m in shards)
+    assert got == dref
+    assert [m.grid() for m in shards] == [ref.grid()] * 2      # spreadMap geometry advances identically
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_halo_blend_and_gathered_save(pf, force_float):
+    torch = pytest.importorskip("torch")
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    base = jitter_poses(9, seed=17, step=(0.0, 0.0))
+    poses = [[(k % 3) * 70.0 + p[0], (k // 3) * 55.0 + p[1]] + p[2:] for k, p in enumerate(base)]
+    frames = [wl.smooth_frame(480, 640, k) ^ wl.noise_frame(480, 640, k) for k in range(len(poses))]
+    (ref,) = build(pf, cam, poses, frames, 1, 1, force_float, scale=2.0)
+    shards = build(pf, cam, poses, frames, 2, 1, force_float, scale=2.0)
+    tiles = ref.tiles()
+    owner = {t: pf.tile_owner(shards[0].opt, *t) for t in tiles}
+    n_remote = 0
+    for t in tiles:
+        me = shards[owner[t]]
+        halos, keep = [0] * 9, []
+        for j, (dx, dy) in enumerate(sh.NEIGHBOURS):
+            nb = (t[0] + dx, t[1] + dy)
+            if (dx, dy) == (0, 0) or nb not in owner or owner[nb] == owner[t]:
+                continue
+            buf = torch.empty(me.halo_bytes(dx, dy), dtype=torch.uint8, device="cuda")
+            assert shards[owner[nb]].halo_pack(nb[0], nb[1], dx, dy, buf.data_ptr())
+            keep.append(buf); halos[j] = buf.data_ptr(); n_remote += 1
+        assert np.array_equal(me.blend_tile_halo(t[0], t[1], halos, raw=True), ref.blend_tile_raw(*t)), t
+        assert np.array_equal(me.blend_tile_halo(t[0], t[1], halos), ref.blend_tile(*t)), t
+    assert n_remote > 0
+    # save(): gather the other shard's tiles, then the whole-mosaic collapse
+    nb = shards[0].tile_bytes()
+    buf = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    for t in shards[1].tiles():
+        assert shards[1].tile_export(t[0], t[1], buf.data_ptr())
+        assert shards[0].tile_import(t[0], t[1], buf.data_ptr())
+    (a, ao), (b, bo) = shards[0].save_to_memory(), ref.save_to_memory()
+    assert ao == bo and np.array_equal(a, b)
