@@ -79,11 +79,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev = local % max(ndev, 1)          # rehearsal on a 1-GPU box: several ranks share the card (PF_DIST_BACKEND=gloo)
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("PF_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     pf = load_package()
     wl = importlib.import_module("pi_slam_fusion_amd.workloads")
@@ -93,7 +99,7 @@ def main():
     height = 100.0
     n_traj = K + W
     block = 128                                     # spatial-hash cell edge in tiles
-    opt = pf.default_options(force_float=force_float, scale=args.scale, device=local,
+    opt = pf.default_options(force_float=force_float, scale=args.scale, device=dev,
                              shard_rank=rank, shard_count=N, shard_block=block)
     m = pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt)
 
@@ -162,7 +168,7 @@ def main():
     barrier()
     dt = t1 - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = m.stats()

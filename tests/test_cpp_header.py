@@ -1,0 +1,41 @@
+"""The header-only C++ face compiles against libpifusion.so with plain g++, with its own
+minimal pi::SE3d and -- when the reference tree is present -- with the reference's own
+pi::SE3d header, and behaves (null map on a box without a device, real tiles on a GPU)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/GSLAM"
+
+
+def build(tmp, extra):
+    exe = os.path.join(tmp, "header_smoke")
+    lib = os.path.join(ROOT, "pi-slam-fusion_amd")
+    cmd = ["g++", "-std=c++11", "-O1", "-I" + os.path.join(ROOT, "include")] + extra + [
+        os.path.join(ROOT, "tests", "cpp", "header_smoke.cpp"), "-o", exe,
+        "-L" + lib, "-l:libpifusion.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def run(exe):
+    return subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+
+
+def test_header_compiles_and_fails_loudly_without_device(pf, tmp_path):
+    r = run(build(str(tmp_path), []))
+    assert r.returncode == 0, r.stdout.decode()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present on this box")
+def test_header_accepts_reference_se3(pf, tmp_path):
+    r = run(build(str(tmp_path), ["-DUSE_REFERENCE_SE3", "-I" + REF]))
+    assert r.returncode == 0, r.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_cpp_face_renders_on_gpu(pf, tmp_path):
+    r = run(build(str(tmp_path), []))
+    assert r.returncode == 0 and b"tiles refreshed" in r.stdout, r.stdout.decode()
