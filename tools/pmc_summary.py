@@ -23,6 +23,9 @@ SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_py
 
 
 def short(name):
+    m = re.search(r"k_level<(\w+), (\w+)>", name)
+    if m:
+        return "level0_fused" if m.group(2) == "true" else "level_fused"
     for k, s in SHORT:
         if k in name:
             return s
