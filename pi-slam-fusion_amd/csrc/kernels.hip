@@ -645,6 +645,196 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
     }
 }
 
+// --------------------------------------------------------------------------
+// k_level3: the same computation as k_level in three stages and two barriers
+//   A  as above
+//   B  G_{i+1} / W_{i+1} straight from A: a thread forms the 7 horizontal 5-tap sums that
+//      two vertically adjacent outputs share, then both vertical sums (no H tile in LDS)
+//   D  one thread = one 2x2 output quad: the 3x3 neighbourhood of G_{i+1} is read once and
+//      serves the four pyrUp parities; one tile-table entry and two 8-byte weight loads per
+//      thread, prefetched after A
+// LDS: A + B only (54 KB fp32 / 40.6 KB int16).
+template <bool F32, bool FROM_WARP>
+__global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
+                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
+                                                 const uint64_t* __restrict__ table)
+{
+    using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
+    using Px = PxT<F32>;
+    __shared__ Px A[LAH][LAW];
+    __shared__ Px Bt[LQH][LQW];
+
+    const int nblk = g.nbx * g.nby;
+    int b = blockIdx.x;
+    {
+        const int per = nblk >> 3;
+        if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
+    }
+    const int bx = b % g.nbx, by = b / g.nbx;
+    const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
+    const int ax0 = x0 - 4, ay0 = y0 - 4;
+    const int nrows = g.rows >> 1, ncols = g.cols >> 1;         // level i+1 extent
+    const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
+    const int tid = threadIdx.x;
+    const int sh = 8 - g.level, ts = kElePixels >> g.level;
+
+    // this thread's output quad and its tile-table entry (a quad never straddles tiles)
+    const int qx = tid & 31, qy = tid >> 5;
+    const int dx0 = x0 + 2 * qx, dy0 = y0 + 2 * qy;
+    uint64_t ent = (dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
+
+    // ---- A
+    const long total = FROM_WARP ? (long)wa.srows * wa.sstep : 0;
+    if constexpr (FROM_WARP) {
+        const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
+        int r = tid / LAW, c = tid - r * LAW;
+        for (int idx = tid; idx < LAH * LAW; idx += LNT) {
+            int y = ay0 + r, x = ax0 + c;
+            if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
+            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; } else
+            A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
+            c += LNT % LAW; r += LNT / LAW;
+            if (c >= LAW) { c -= LAW; r++; }
+        }
+    } else {
+        // six named pixels (not an array: arrays of this struct end up in scratch): every load of
+        // the thread is issued before the first LDS store
+        constexpr int NIT = (LAH * LAW + LNT - 1) / LNT;
+        static_assert(NIT == 6, "staging below is written for 6 passes");
+        const Px* __restrict__ gin = gw_in;
+        Px* Aflat = &A[0][0];
+        auto gaddr = [&](int idx) {
+            const int r = idx / LAW, c = idx - r * LAW;
+            const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
+            return (long)y * g.cols + x;
+        };
+        const bool last = tid + 5 * LNT < LAH * LAW;
+        const Px t0 = gin[gaddr(tid)], t1 = gin[gaddr(tid + LNT)], t2 = gin[gaddr(tid + 2 * LNT)];
+        const Px t3 = gin[gaddr(tid + 3 * LNT)], t4 = gin[gaddr(tid + 4 * LNT)];
+        const Px t5 = gin[gaddr(last ? tid + 5 * LNT : tid)];
+        Aflat[tid] = t0; Aflat[tid + LNT] = t1; Aflat[tid + 2 * LNT] = t2; Aflat[tid + 3 * LNT] = t3; Aflat[tid + 4 * LNT] = t4;
+        if (last) Aflat[tid + 5 * LNT] = t5;
+    }
+    lds_barrier();
+    if (g.ablate & 2) return;
+
+    // stored weights of the quad: in flight during stage B
+    float dwv[2][2] = { { -1.f, -1.f }, { -1.f, -1.f } };           // fresh tile: every weight (>= 0) wins
+    const uint64_t slot = ent & ~(uint64_t)1;
+    const int loc0 = (dy0 & (ts - 1)) * ts + (dx0 & (ts - 1));
+    if (ent && !(ent & 1)) {
+        const float PF_GLOBAL* wp = (const float PF_GLOBAL*)(slot + lay.w_off[g.level]) + loc0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 v = *(const f2 PF_GLOBAL*)(wp + j * ts);
+            dwv[j][0] = v.x; dwv[j][1] = v.y;
+        }
+    }
+
+    // ---- B: two vertically adjacent outputs per thread
+    const int vec_img = (ncols * 3 / 8) * 8, vec_w = (ncols / 8) * 8;     // PyrDownVec_32f coverage
+    for (int idx = tid; idx < (LQH / 2) * LQW; idx += LNT) {
+        const int pp = idx / LQW, q = idx - pp * LQW;
+        const int X = bx0 + q;
+        if (X < 0 || X >= ncols) continue;
+        WT h[7][3]; float hw[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const Px* row = &A[4 * pp + j][2 * q];
+            const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) h[j][k] = (WT)a2.c[k] * 6 + ((WT)a1.c[k] + (WT)a3.c[k]) * 4 + (WT)a0.c[k] + (WT)a4.c[k];
+            hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int p = 2 * pp + e, Y = by0 + p;
+            if (Y < 0 || Y >= nrows) continue;
+            Px o;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const WT r0 = h[2 * e][k], r1 = h[2 * e + 1][k], r2 = h[2 * e + 2][k], r3 = h[2 * e + 3][k], r4 = h[2 * e + 4][k];
+                if constexpr (F32) {
+                    if (X * 3 + k < vec_img) {
+                        float a = r0 + r4;
+                        const float bb = (r1 + r3) + r2;
+                        a = a + (r2 + r2);
+                        o.c[k] = (a + bb * 4.f) * (1.f / 256);
+                    } else
+                        o.c[k] = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
+                } else
+                    o.c[k] = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
+            }
+            {
+                const float r0 = hw[2 * e], r1 = hw[2 * e + 1], r2 = hw[2 * e + 2], r3 = hw[2 * e + 3], r4 = hw[2 * e + 4];
+                if (X < vec_w) {
+                    float a = r0 + r4;
+                    const float bb = (r1 + r3) + r2;
+                    a = a + (r2 + r2);
+                    o.w = (a + bb * 4.f) * (1.f / 256);
+                } else
+                    o.w = (r2 * 6 + (r1 + r3) * 4 + r0 + r4) * (1.f / 256);
+            }
+            if constexpr (!F32) o.pad = 0;
+            Bt[p][q] = o;
+            if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
+                if (g.write_next) gw_out[(long)Y * ncols + X] = o;
+                if (g.top_select) select_store<F32>(lay, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+            }
+        }
+    }
+    lds_barrier();
+    if (g.ablate & 4) return;
+
+    // ---- D: 2x2 quad, Laplacian + max-weight select
+    if (!ent) return;
+    const Px g00 = A[2 * qy + 4][2 * qx + 4], g01 = A[2 * qy + 4][2 * qx + 5];
+    const Px g10 = A[2 * qy + 5][2 * qx + 4], g11 = A[2 * qy + 5][2 * qx + 5];
+    const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
+    const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
+    const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
+    if (!(s00 || s01 || s10 || s11)) return;
+    const int sy = dy0 >> 1, sx = dx0 >> 1;
+    int syn = sy + 1; if (syn >= nrows) syn = nrows - 1;
+    int syp = sy - 1; if (syp < 0) syp = nrows > 1 ? 1 : 0;
+    const bool one = ncols == 1, le = sx == 0, re = sx == ncols - 1;
+    const bool edge = le || re;
+    const int j = qx + 1;                                    // B column of sx
+    // int16: edge forms are the interior form on reflected (left) / replicated (right) neighbours
+    const int ja = (le && !F32) ? (one ? j : j + 1) : j - 1, jc = (re && !F32) ? j : j + 1;
+    const int rows3[3] = { syp - by0, sy - by0, syn - by0 };
+    WT he[3][3], ho[3][3];                                   // [row][channel]: even / odd output column
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const Px a = Bt[rows3[r]][ja], bq = Bt[rows3[r]][j], c = Bt[rows3[r]][jc];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (F32 && edge) {
+                he[r][k] = up_h_val<WT, true>((WT)a.c[k], (WT)bq.c[k], (WT)c.c[k], false, le, re, one);
+                ho[r][k] = up_h_val<WT, true>((WT)a.c[k], (WT)bq.c[k], (WT)c.c[k], true, le, re, one);
+            } else {
+                he[r][k] = up_h_val<WT, false>((WT)a.c[k], (WT)bq.c[k], (WT)c.c[k], false, false, false, false);
+                ho[r][k] = up_h_val<WT, false>((WT)a.c[k], (WT)bq.c[k], (WT)c.c[k], true, false, false, false);
+            }
+        }
+    }
+    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[g.level]) + loc0 * 3;
+    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off[g.level]) + loc0;
+    T o00[3], o01[3], o10[3], o11[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o00[k] = sat_sub(g00.c[k], cast_up(he[0][k] + he[1][k] * 6 + he[2][k]));
+        o01[k] = sat_sub(g01.c[k], cast_up(ho[0][k] + ho[1][k] * 6 + ho[2][k]));
+        o10[k] = sat_sub(g10.c[k], cast_up((he[1][k] + he[2][k]) * 4));
+        o11[k] = sat_sub(g11.c[k], cast_up((ho[1][k] + ho[2][k]) * 4));
+    }
+    if (s00) { dl[0] = o00[0]; dl[1] = o00[1]; dl[2] = o00[2]; dw[0] = g00.w; }
+    if (s01) { dl[3] = o01[0]; dl[4] = o01[1]; dl[5] = o01[2]; dw[1] = g01.w; }
+    if (s10) { dl[3 * ts] = o10[0]; dl[3 * ts + 1] = o10[1]; dl[3 * ts + 2] = o10[2]; dw[ts] = g10.w; }
+    if (s11) { dl[3 * ts + 3] = o11[0]; dl[3 * ts + 4] = o11[1]; dl[3 * ts + 5] = o11[2]; dw[ts + 1] = g11.w; }
+}
+
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
@@ -661,13 +851,21 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     dim3 grid(g.nbx * g.nby), block(LNT);
     WarpArgs w{};
     if (wa) w = *wa;
-    if (lay.f32) {
-        if (wa) hipLaunchKernelGGL((k_level<true, true>), grid, block, 0, s, lay, g, w, src, (const PxT<true>*)gw_in, (PxT<true>*)gw_out, table);
-        else    hipLaunchKernelGGL((k_level<true, false>), grid, block, 0, s, lay, g, w, src, (const PxT<true>*)gw_in, (PxT<true>*)gw_out, table);
+    // Two code shapes of the same computation: k_level (4 barriers, 58 VGPRs) and k_level3
+    // (2 barriers, no H tile; 96 VGPRs for int16, 128 + spills for fp32).  Measured on MI355X:
+    // k_level3 wins everywhere except the fp32 warp level, where its register pressure hurts
+    // the VALU-bound warp stage.  PF_KLEVEL=4|3 forces one shape (diagnostics).
+    static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
+    const bool use4 = force == 4 || (force != 3 && lay.f32 && wa);
+#define PF_LAUNCH(K, F, W) hipLaunchKernelGGL((K<F, W>), grid, block, 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
+    if (use4) {
+        if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true); else PF_LAUNCH(k_level, true, false); }
+        else         { if (wa) PF_LAUNCH(k_level, false, true); else PF_LAUNCH(k_level, false, false); }
     } else {
-        if (wa) hipLaunchKernelGGL((k_level<false, true>), grid, block, 0, s, lay, g, w, src, (const PxT<false>*)gw_in, (PxT<false>*)gw_out, table);
-        else    hipLaunchKernelGGL((k_level<false, false>), grid, block, 0, s, lay, g, w, src, (const PxT<false>*)gw_in, (PxT<false>*)gw_out, table);
+        if (lay.f32) { if (wa) PF_LAUNCH(k_level3, true, true); else PF_LAUNCH(k_level3, true, false); }
+        else         { if (wa) PF_LAUNCH(k_level3, false, true); else PF_LAUNCH(k_level3, false, false); }
     }
+#undef PF_LAUNCH
 }
 
 // ------------------------------------------------------------------ blend
