@@ -310,7 +310,7 @@ template <> struct alignas(16) PxT<true>  { float c[3]; float w; };
 template <> struct alignas(4)  PxT<false> { short c[3]; short pad; float w; };
 template <bool F32> struct alignas(16) HxT { typename Pix<F32>::WT c[3]; float w; };
 
-constexpr int LBW = 64, LBH = 32, LAW = LBW + 7, LAH = LBH + 7, LQW = LBW / 2 + 2, LQH = LBH / 2 + 2, LNT = 512;
+constexpr int LBW = 64, LAW = LBW + 7, LQW = LBW / 2 + 2;      // block width, staged width, half-size width (+halo)
 
 struct LevelArgs {
     int level, rows, cols;        // level i and its canvas extent
@@ -324,7 +324,7 @@ struct LevelArgs {
 
 // one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
 template <bool F32>
-__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const WarpArgs& a, long total, int x, int y)
+__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const WarpArgs& a, long total, int x, int y, int abl = 0)
 {
     using T = typename Pix<F32>::T;
     PxT<F32> o;
@@ -334,7 +334,8 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
     const double W  = W0 + a.M[6] * x1;
     const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
-    const double Wn = W ? 1. / W : 0;
+    double Wn = W ? 1. / W : 0;
+    if (abl & 32) Wn = (double)(1.f / (float)W);
     // nearest coordinate p = (X0+M0*x1)*(1/W); the 1/32-px coordinate (X0+M0*x1)*(32/W) equals 32*p
     // bit for bit (32/W == 32*(1/W) and scaling by a power of two commutes with rounding).
     // v_cvt_i32_f64 saturates, which is exactly clamp-to-int-range followed by cvRound.
@@ -342,6 +343,7 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     {
         const int sx = sat_short(__double2int_rn(pxn)), sy = sat_short(__double2int_rn(pyn));
         float wv = 0.f;
+        if (abl & 8) wv = (float)(sx + sy); else
         if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
             const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
             float dis = dy * dy + dx * dx;
@@ -358,7 +360,9 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
     float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
     // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes 3..5
-    const long off0 = (long)sy * a.sstep + 3L * sx;
+    // frames are < 2 GiB and rows/steps fit 24 bits: 32-bit offsets, full-rate 24-bit multiplies
+    const int step32 = (int)a.sstep;
+    const long off0 = (long)(__mul24(sy, step32) + 3 * sx);
     const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1) &&
                       off0 + a.sstep + 8 <= total;
     if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
@@ -366,6 +370,7 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             uint64_t bits;
+            if (abl & 16) bits = (uint64_t)off0 * 0x9E3779B97F4A7C15ull; else
             __builtin_memcpy(&bits, src + off0 + (j ? a.sstep : 0), 8);
             const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
             v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
@@ -382,7 +387,7 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         const bool t0hi = sx0 != xbase, t1hi = sx1 != xbase;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const long off = (long)(j ? sy1 : sy0) * a.sstep + 3L * xbase;
+            const long off = (long)(__mul24(j ? sy1 : sy0, step32) + 3 * xbase);
             uint64_t bits;
             if (off + 8 > total) {           // last bytes of the frame: never read past it
                 const int back = (int)(off + 8 - total);
@@ -455,13 +460,39 @@ __device__ __forceinline__ void select_store(const TileLayout& lay, int level, c
 // (the D-stage weight prefetch) stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool F32, bool FROM_WARP>
+// stage A for levels >= 1: GW_i block + halo from HBM into LDS.  Named pixels (not an array:
+// arrays of this struct end up in scratch), four loads in flight per thread before their LDS stores.
+template <bool F32, int LAH, int LNT>
+__device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, const PxT<F32>* __restrict__ gin,
+                                               int ax0, int ay0, int rows, int cols, int tid)
+{
+    using Px = PxT<F32>;
+    auto gaddr = [&](int idx) {
+        idx = idx < LAH * LAW ? idx : tid;
+        const int r = idx / LAW, c = idx - r * LAW;
+        const int y = border_reflect101(ay0 + r, rows), x = border_reflect101(ax0 + c, cols);
+        return (long)y * cols + x;
+    };
+#pragma unroll
+    for (int base = 0; base < LAH * LAW; base += 4 * LNT) {
+        const int i0 = base + tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT;
+        const Px t0 = gin[gaddr(i0)], t1 = gin[gaddr(i1)], t2 = gin[gaddr(i2)], t3 = gin[gaddr(i3)];
+        if (i0 < LAH * LAW) Aflat[i0] = t0;
+        if (i1 < LAH * LAW) Aflat[i1] = t1;
+        if (i2 < LAH * LAW) Aflat[i2] = t2;
+        if (i3 < LAH * LAW) Aflat[i3] = t3;
+    }
+}
+
+template <bool F32, bool FROM_WARP, int LBH, int LNT>
 __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
                                                 const uint64_t* __restrict__ table)
 {
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>; using Hx = HxT<F32>;
+    constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
+    static_assert((LBH * LBW) % LNT == 0, "D stage: whole passes");
     __shared__ Px A[LAH][LAW];
     __shared__ Hx Ht[LAH][LQW];
     __shared__ Px Bt[LQH][LQW];
@@ -501,29 +532,13 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         for (int idx = tid; idx < LAH * LAW; idx += LNT) {
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
-            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; } else
-            A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
+            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, total, x, y, g.ablate);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
     } else {
-        // all of a thread's loads are issued before the first LDS store
-        constexpr int NIT = (LAH * LAW + LNT - 1) / LNT;
-        Px tmp[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = tid + it * LNT;
-            if (idx < LAH * LAW) {
-                const int r = idx / LAW, c = idx - r * LAW;
-                const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
-                tmp[it] = gw_in[(long)y * g.cols + x];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = tid + it * LNT;
-            if (idx < LAH * LAW) { const int r = idx / LAW, c = idx - r * LAW; A[r][c] = tmp[it]; }
-        }
+        stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
     }
     lds_barrier();
     if (g.ablate & 2) return;
@@ -654,13 +669,15 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
 //      serves the four pyrUp parities; one tile-table entry and two 8-byte weight loads per
 //      thread, prefetched after A
 // LDS: A + B only (54 KB fp32 / 40.6 KB int16).
-template <bool F32, bool FROM_WARP>
+template <bool F32, bool FROM_WARP, int LBH, int LNT>
 __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
                                                  const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
                                                  const uint64_t* __restrict__ table)
 {
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
+    constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
+    static_assert(LNT == 32 * (LBH / 2), "one thread per 2x2 output quad");
     __shared__ Px A[LAH][LAW];
     __shared__ Px Bt[LQH][LQW];
 
@@ -691,29 +708,13 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
         for (int idx = tid; idx < LAH * LAW; idx += LNT) {
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
-            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; } else
-            A[r][c] = warp_pixel<F32>(src, wa, total, x, y);
+            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, total, x, y, g.ablate);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
     } else {
-        // six named pixels (not an array: arrays of this struct end up in scratch): every load of
-        // the thread is issued before the first LDS store
-        constexpr int NIT = (LAH * LAW + LNT - 1) / LNT;
-        static_assert(NIT == 6, "staging below is written for 6 passes");
-        const Px* __restrict__ gin = gw_in;
-        Px* Aflat = &A[0][0];
-        auto gaddr = [&](int idx) {
-            const int r = idx / LAW, c = idx - r * LAW;
-            const int y = border_reflect101(ay0 + r, g.rows), x = border_reflect101(ax0 + c, g.cols);
-            return (long)y * g.cols + x;
-        };
-        const bool last = tid + 5 * LNT < LAH * LAW;
-        const Px t0 = gin[gaddr(tid)], t1 = gin[gaddr(tid + LNT)], t2 = gin[gaddr(tid + 2 * LNT)];
-        const Px t3 = gin[gaddr(tid + 3 * LNT)], t4 = gin[gaddr(tid + 4 * LNT)];
-        const Px t5 = gin[gaddr(last ? tid + 5 * LNT : tid)];
-        Aflat[tid] = t0; Aflat[tid + LNT] = t1; Aflat[tid + 2 * LNT] = t2; Aflat[tid + 3 * LNT] = t3; Aflat[tid + 4 * LNT] = t4;
-        if (last) Aflat[tid + 5 * LNT] = t5;
+        stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
     }
     lds_barrier();
     if (g.ablate & 2) return;
@@ -844,26 +845,27 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     LevelArgs g{};
     g.level = level; g.rows = rows; g.cols = cols; g.cx0 = cx0; g.cy0 = cy0; g.cx1 = cx1; g.cy1 = cy1;
     g.tiles_x = tiles_x; g.top_select = top_select; g.write_next = write_next;
-    g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + LBH - 1) / LBH;
+    // Two code shapes of the same computation: k_level (4 barriers, H tile in LDS, ~50 VGPRs) and
+    // k_level3 (2 barriers, no H tile, 2x2 output quads; 96 VGPRs int16, 128 + spills fp32).
+    // Measured on MI355X (cfg-A): fp32 is fastest with k_level on 64x16 blocks (3 workgroups per
+    // CU), int16 with k_level3 on 64x32 blocks.  PF_KLEVEL=4|3 forces one shape (diagnostics).
+    static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
+    const bool use4 = force == 4 || (force != 3 && lay.f32);
+    const int BH = use4 ? 16 : 32;
+    g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + BH - 1) / BH;
     g.ablate = ablate;
     if (g.nbx <= 0 || g.nby <= 0) return;
-    dim3 grid(g.nbx * g.nby), block(LNT);
+    dim3 grid(g.nbx * g.nby);
     WarpArgs w{};
     if (wa) w = *wa;
-    // Two code shapes of the same computation: k_level (4 barriers, 58 VGPRs) and k_level3
-    // (2 barriers, no H tile; 96 VGPRs for int16, 128 + spills for fp32).  Measured on MI355X:
-    // k_level3 wins everywhere except the fp32 warp level, where its register pressure hurts
-    // the VALU-bound warp stage.  PF_KLEVEL=4|3 forces one shape (diagnostics).
-    static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
-    const bool use4 = force == 4 || (force != 3 && lay.f32 && wa);
-#define PF_LAUNCH(K, F, W) hipLaunchKernelGGL((K<F, W>), grid, block, 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
+#define PF_LAUNCH(K, F, W, H, NT) hipLaunchKernelGGL((K<F, W, H, NT>), grid, dim3(NT), 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
     if (use4) {
-        if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true); else PF_LAUNCH(k_level, true, false); }
-        else         { if (wa) PF_LAUNCH(k_level, false, true); else PF_LAUNCH(k_level, false, false); }
+        if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true, 16, 512); else PF_LAUNCH(k_level, true, false, 16, 512); }
+        else         { if (wa) PF_LAUNCH(k_level, false, true, 16, 512); else PF_LAUNCH(k_level, false, false, 16, 512); }
     } else {
-        if (lay.f32) { if (wa) PF_LAUNCH(k_level3, true, true); else PF_LAUNCH(k_level3, true, false); }
-        else         { if (wa) PF_LAUNCH(k_level3, false, true); else PF_LAUNCH(k_level3, false, false); }
+        if (lay.f32) { if (wa) PF_LAUNCH(k_level3, true, true, 32, 512); else PF_LAUNCH(k_level3, true, false, 32, 512); }
+        else         { if (wa) PF_LAUNCH(k_level3, false, true, 32, 512); else PF_LAUNCH(k_level3, false, false, 32, 512); }
     }
 #undef PF_LAUNCH
 }
