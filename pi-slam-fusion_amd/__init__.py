@@ -18,7 +18,7 @@ ELE_PIXELS = 256
 
 # Map2D::Map2DType (Map2D.h:83)
 NoType, TypeCPU, TypeGPU, TypeMultiBandCPU, TypeRender = 0, 1, 2, 3, 4
-PF_8UC3, PF_16SC3, PF_32FC3 = 16, 19, 21
+PF_8UC3, PF_8UC4, PF_16SC3, PF_32FC3 = 16, 24, 19, 21
 
 
 class Options(C.Structure):
@@ -186,12 +186,14 @@ class Map2D:
         return bool(lib().pf_prepare(self._h, ppl, pc, ps.shape[0], imgs, ps.ctypes.data_as(C.POINTER(C.c_double))))
 
     def feed(self, img, pose):
-        """img: HxWx3 uint8 BGR numpy array (host), or None for a geometry-only frame."""
+        """img: HxWx3 (BGR) or HxWx4 (BGRA) uint8 numpy array (host), or None for a geometry-only frame."""
         p, pp = _pose(pose)
         if img is None:
             return bool(lib().pf_feed(self._h, None, pp))
         img = np.ascontiguousarray(img)
-        typ = PF_8UC3 if (img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3) else -1
+        typ = -1
+        if img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] in (3, 4):
+            typ = PF_8UC3 if img.shape[2] == 3 else PF_8UC4      # BGRA as the tracker holds it (TrackerOpt.cpp:376)
         im = Image(img.shape[0], img.shape[1], typ, img.ctypes.data, 0)
         return bool(lib().pf_feed(self._h, C.byref(im), pp))
 

@@ -272,11 +272,12 @@ bool FusionMap::prepare(const double plane7[7], const double cam[6], int n, cons
         // with a render thread the prepare frames are rendered first (Map2D.cpp:42, .cpp:606-615)
         for (int i = 0; i < n; i++) {
             if (!imgs[i].data) continue;
-            const int slot = acquire_slot((size_t)imgs[i].rows * imgs[i].cols * 3);
+            const int cn = imgs[i].type == PF_8UC4 ? 4 : 3;
+            const int slot = acquire_slot((size_t)imgs[i].rows * imgs[i].cols * cn);
             if (slot < 0 || !upload(&imgs[i], slot)) return false;
             std::lock_guard<std::mutex> q(qmu_);
             slots_[slot].queued = true;
-            queue_.push_back({ slot, nullptr, (long)imgs[i].cols * 3, imgs[i].rows, imgs[i].cols, local[i] });
+            queue_.push_back({ slot, nullptr, (long)imgs[i].cols * cn, imgs[i].rows, imgs[i].cols, cn, local[i] });
         }
         qcv_.notify_all();
     }
@@ -322,7 +323,7 @@ int FusionMap::acquire_slot(size_t bytes)
 
 bool FusionMap::upload(const pf_image* img, int slot)
 {
-    const size_t row = (size_t)img->cols * 3, step = img->step ? img->step : row;
+    const size_t row = (size_t)img->cols * (img->type == PF_8UC4 ? 4 : 3), step = img->step ? img->step : row;
     HIP_OK(hipMemcpy2DAsync(slots_[slot].dev, row, img->data, step, row, img->rows, hipMemcpyHostToDevice, copy_stream_));
     // the caller may release its pixels when feed() returns
     HIP_OK(hipStreamSynchronize(copy_stream_));
@@ -343,7 +344,8 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
         if (img) {
             // wrong size/type is reported by renderFrame (.cpp:319-323); keep that order of checks
             f.rows = img->rows; f.cols = img->cols;
-            if (img->type != PF_8UC3 || img->cols != cam_.w || img->rows != cam_.h) {
+            f.cn = img->type == PF_8UC4 ? 4 : 3;     // BGRA frames are accepted as the tracker produces them (row f1)
+            if ((img->type != PF_8UC3 && img->type != PF_8UC4) || img->cols != cam_.w || img->rows != cam_.h) {
                 std::fprintf(stderr, "MultiBandMap2DCPU::renderFrame: frame.first.cols!=p->_camera.w||frame.first.rows!=p->_camera.h||frame.first.type()!=CV_8UC3\n");
                 if (!thread_) { n_rejected_++; return false; }
                 return true;    // the threaded reference enqueues and fails later on the render thread
@@ -351,11 +353,11 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
             if (img->data) {
                 if (device_ptr) {
                     if (thread_) { set_error("pf_feed_device needs a thread=0 map"); return false; }
-                    f.ext = (const uint8_t*)img->data; f.step = img->step ? (long)img->step : (long)img->cols * 3;
+                    f.ext = (const uint8_t*)img->data; f.step = img->step ? (long)img->step : (long)img->cols * f.cn;
                 } else {
-                    f.slot = acquire_slot((size_t)img->rows * img->cols * 3);
+                    f.slot = acquire_slot((size_t)img->rows * img->cols * f.cn);
                     if (f.slot < 0 || !upload(img, f.slot)) return false;
-                    f.step = (long)img->cols * 3;
+                    f.step = (long)img->cols * f.cn;
                 }
             }
         }
@@ -566,6 +568,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     a.xc = (float)(f.cols / 2); a.yc = (float)(f.rows / 2);
     a.dis_max = std::sqrt(a.xc * a.xc + a.yc * a.yc);
     a.weight_type = opt_.weight_type;
+    a.src_cn = f.cn == 4 ? 4 : 3;
     if (fused) {
         // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
@@ -605,7 +608,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kTableRing)], 0));
             // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
             double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
-            if (i == 0) bytes += 3.0 * f.rows * f.cols;
+            if (i == 0) bytes += (double)a.src_cn * f.rows * f.cols;
             prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
             launch_level(st, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
                          i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab);

@@ -64,7 +64,7 @@ struct QueuedFrame {
     int    slot;            // index into frame slots, -1 = geometry only
     const uint8_t* ext;     // externally owned device pointer (pf_feed_device) or nullptr
     long   step;
-    int    rows, cols;
+    int    rows, cols, cn;  // cn: 3 = BGR8, 4 = BGRA8
     Pose   pose;            // plane coordinates
 };
 

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t* __restrict__ src, W
         const uint8_t* r1 = src + (long)sy1 * a.sstep;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            float v0 = (float)r0[sx0 * 3 + k], v1 = (float)r0[sx1 * 3 + k];
-            float v2 = (float)r1[sx0 * 3 + k], v3 = (float)r1[sx1 * 3 + k];
+            float v0 = (float)r0[sx0 * a.src_cn + k], v1 = (float)r0[sx1 * a.src_cn + k];
+            float v2 = (float)r1[sx0 * a.src_cn + k], v3 = (float)r1[sx1 * a.src_cn + k];
             if (F32) {
                 const float s = (float)(1. / 255.);
                 v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
@@ -362,7 +362,8 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes 3..5
     // frames are < 2 GiB and rows/steps fit 24 bits: 32-bit offsets, full-rate 24-bit multiplies
     const int step32 = (int)a.sstep;
-    const long off0 = (long)(__mul24(sy, step32) + 3 * sx);
+    const int cn = a.src_cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
+    const long off0 = (long)(__mul24(sy, step32) + cn * sx);
     const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1) &&
                       off0 + a.sstep + 8 <= total;
     if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
@@ -372,9 +373,9 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
             uint64_t bits;
             if (abl & 16) bits = (uint64_t)off0 * 0x9E3779B97F4A7C15ull; else
             __builtin_memcpy(&bits, src + off0 + (j ? a.sstep : 0), 8);
-            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            const uint32_t lo = (uint32_t)bits, hi = cn == 3 ? (uint32_t)(bits >> 24) : (uint32_t)(bits >> 32);
             v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
-            v[2 * j + 1][0] = (float)(lo >> 24); v[2 * j + 1][1] = (float)(hi & 0xff); v[2 * j + 1][2] = (float)((hi >> 8) & 0xff);
+            v[2 * j + 1][0] = (float)(hi & 0xff); v[2 * j + 1][1] = (float)((hi >> 8) & 0xff); v[2 * j + 1][2] = (float)((hi >> 16) & 0xff);
         }
     } else {
         int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
@@ -387,7 +388,7 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         const bool t0hi = sx0 != xbase, t1hi = sx1 != xbase;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const long off = (long)(__mul24(j ? sy1 : sy0, step32) + 3 * xbase);
+            const long off = (long)(__mul24(j ? sy1 : sy0, step32) + cn * xbase);
             uint64_t bits;
             if (off + 8 > total) {           // last bytes of the frame: never read past it
                 const int back = (int)(off + 8 - total);
@@ -395,9 +396,9 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
                 bits >>= 8 * back;
             } else
                 __builtin_memcpy(&bits, src + off, 8);
-            const uint32_t lo = (uint32_t)bits, hi = (uint32_t)(bits >> 32);
+            const uint32_t lo = (uint32_t)bits, hi = cn == 3 ? (uint32_t)(bits >> 24) : (uint32_t)(bits >> 32);
             const float l0 = (float)(lo & 0xff), l1 = (float)((lo >> 8) & 0xff), l2 = (float)((lo >> 16) & 0xff);
-            const float h0 = (float)(lo >> 24), h1 = (float)(hi & 0xff), h2 = (float)((hi >> 8) & 0xff);
+            const float h0 = (float)(hi & 0xff), h1 = (float)((hi >> 8) & 0xff), h2 = (float)((hi >> 16) & 0xff);
             v[2 * j][0] = t0hi ? h0 : l0; v[2 * j][1] = t0hi ? h1 : l1; v[2 * j][2] = t0hi ? h2 : l2;
             v[2 * j + 1][0] = t1hi ? h0 : l0; v[2 * j + 1][1] = t1hi ? h1 : l1; v[2 * j + 1][2] = t1hi ? h2 : l2;
         }

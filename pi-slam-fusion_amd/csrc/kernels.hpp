@@ -38,6 +38,7 @@ struct WarpArgs {
     int    wrows, wcols;    // window extent (multiple of 4 rows / 64 cols)
     float  xc, yc, dis_max; // radial weight constants (MultiBandMap2DCPU.cpp:404-406)
     int    weight_type;
+    int    src_cn;          // 3 = BGR8, 4 = BGRA8 (alpha ignored: the tracker's cvtColor BGRA2BGR, TrackerOpt.cpp:376-380, done in the gather)
 };
 
 // a source of blend() pixels: a tile slot or a packed halo strip set

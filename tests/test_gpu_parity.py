@@ -76,7 +76,7 @@ def test_rejections(pf, orc):
     assert g.prepare(wl.IDENTITY_PLANE, [640, 480, 0, 500, 320, 240], poses) is False
     assert g.prepare(wl.IDENTITY_PLANE, cam, poses)
     assert g.feed(wl.noise_frame(240, 320, 0), poses[0]) is False  # wrong size
-    assert g.feed(np.zeros((480, 640, 4), np.uint8), poses[0]) is False  # wrong type
+    assert g.feed(np.zeros((480, 640, 1), np.uint8), poses[0]) is False  # wrong type
     s = np.sin(np.radians(80) / 2); c = np.cos(np.radians(80) / 2)
     assert g.feed(img, [0, 0, -100, s, 0, 0, c]) is False       # oblique view
     assert g.feed(img, poses[0]) is True
