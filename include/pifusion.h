@@ -63,8 +63,9 @@ void    pf_default_options(pf_options* o);
 /* key=value setter accepting the reference's svar key names
  * ("MultiBandMap2DCPU.BandNumber", "Map2D.Scale", ...); 1 if the key is known */
 int     pf_options_set(pf_options* o, const char* key, const char* value);
-/* Map2D::create(type, thread), Map2DFusion/Map2D.cpp:51-66.  Types CPU/GPU/
- * MULTIBAND all map onto the multi-band GPU engine; NONE/RENDER -> NULL.   */
+/* Map2D::create(type, thread), Map2DFusion/Map2D.cpp:51-66.  MULTIBAND -> the multi-band
+ * engine; CPU -> Map2DCPU semantics (single 8-bit band); GPU -> the same, as the reference
+ * itself falls back ("CUDA is not enabled, switch to CPU"); NONE/RENDER -> NULL.        */
 pf_map* pf_create(int type, int thread, const pf_options* opt);
 void    pf_destroy(pf_map* m);
 const char* pf_last_error(void);
@@ -105,6 +106,9 @@ int     pf_tile_count(pf_map* m);
 int     pf_tile_coords(pf_map* m, int* xy, int cap);
 /* Ele::pyr_laplace[level] / Ele::weights[level]: D2H copy of one level.    */
 int     pf_get_tile_level(pf_map* m, int ix, int iy, int level, void* lap, float* w);
+/* Map2DCPU::Map2DCPUEle::img (Map2DFusion/Map2DCPU.h): the 256x256 BGRA tile of a
+ * TypeCPU / TypeGPU map (alpha = winning weight byte).                      */
+int     pf_get_tile_bgra(pf_map* m, int ix, int iy, uint8_t* bgra256);
 /* Ele::blend(neighbors), .cpp:77-146: raw result in the pyramid type.      */
 int     pf_blend_tile_raw(pf_map* m, int ix, int iy, void* out);
 /* Ele::updateTexture's pixels, .cpp:149-160: blend -> BGR8 256x256.        */

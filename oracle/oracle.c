@@ -194,6 +194,81 @@ void orc_warp_nearest_const_32f(const float* src, int srows, int scols, int cn,
     }
 }
 
+/* ---- 8-bit fixed-point bilinear remap (imgwarp.cpp remapBilinear<FixedPtCast<int,uchar,15>,...,short>) ----
+ * integer tap weights = saturate_cast<short>(w*32768); all bilinear products on the 1/32 grid are exact
+ * integers summing to 32768 except at (0,0), where 32768 saturates to 32767 and initInterTab2D's fix-up
+ * adds the missing 1 to another tap -- neither changes any output ((S*32767 + T + 16384) >> 15 == S). */
+static void orc_itab(int fxi, int fyi, int w[4])
+{
+    const float fx = fxi * (1.f / 32), fy = fyi * (1.f / 32);
+    const float v[4] = { (1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx };
+    int sum = 0;
+    for (int k = 0; k < 4; k++) { int t = orc_cvround((double)(v[k] * 32768.f)); w[k] = t > 32767 ? 32767 : t; sum += w[k]; }
+    if (sum != 32768) w[3] += 32768 - sum;
+}
+
+void orc_warp_linear_const_8u(const uint8_t* src, int srows, int scols, int cn,
+                              uint8_t* dst, int drows, int dcols, const double M0[9])
+{
+    double M[9];
+    if (!orc_invert3x3(M0, M)) memset(M, 0, sizeof(M));
+    int bh0 = drows < 16 ? drows : 16;
+    int bw0 = (1024 / bh0) < dcols ? (1024 / bh0) : dcols;
+    const size_t sstep = (size_t)scols * cn;
+    for (int y = 0; y < drows; y++) {
+        uint8_t* D = dst + (size_t)y * dcols * cn;
+        for (int xb = 0; xb < dcols; xb += bw0) {
+            const int bw = bw0 < dcols - xb ? bw0 : dcols - xb;
+            const double X0 = M[0] * xb + M[1] * y + M[2];
+            const double Y0 = M[3] * xb + M[4] * y + M[5];
+            const double W0 = M[6] * xb + M[7] * y + M[8];
+            for (int x1 = 0; x1 < bw; x1++) {
+                double W = W0 + M[6] * x1;
+                W = W ? 32. / W : 0;
+                double fX = (X0 + M[0] * x1) * W, fY = (Y0 + M[3] * x1) * W;
+                fX = fX < (double)INT_MAX ? fX : (double)INT_MAX; fX = fX > (double)INT_MIN ? fX : (double)INT_MIN;
+                fY = fY < (double)INT_MAX ? fY : (double)INT_MAX; fY = fY > (double)INT_MIN ? fY : (double)INT_MIN;
+                const int X = orc_cvround(fX), Y = orc_cvround(fY);
+                const int sx = orc_sat_short(X >> 5), sy = orc_sat_short(Y >> 5);
+                int w[4];
+                orc_itab(X & 31, Y & 31, w);
+                uint8_t* d = D + (size_t)(xb + x1) * cn;
+                if (sx >= scols || sx + 1 < 0 || sy >= srows || sy + 1 < 0) {
+                    for (int k = 0; k < cn; k++) d[k] = 0;
+                    continue;
+                }
+                const int in00 = sx >= 0 && sy >= 0, in01 = sx + 1 < scols && sy >= 0;
+                const int in10 = sx >= 0 && sy + 1 < srows, in11 = sx + 1 < scols && sy + 1 < srows;
+                for (int k = 0; k < cn; k++) {
+                    const int v0 = in00 ? src[(size_t)sy * sstep + (size_t)sx * cn + k] : 0;
+                    const int v1 = in01 ? src[(size_t)sy * sstep + (size_t)(sx + 1) * cn + k] : 0;
+                    const int v2 = in10 ? src[(size_t)(sy + 1) * sstep + (size_t)sx * cn + k] : 0;
+                    const int v3 = in11 ? src[(size_t)(sy + 1) * sstep + (size_t)(sx + 1) * cn + k] : 0;
+                    d[k] = orc_sat_uchar((v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + (1 << 14)) >> 15);
+                }
+            }
+        }
+    }
+}
+
+/* Map2DCPU.cpp:245-263 */
+void orc_weight_image_8uc4(uint8_t* p, int h, int w, int weight_type)
+{
+    float x_center = w / 2;
+    float y_center = h / 2;
+    float dis_max = sqrtf(x_center * x_center + y_center * y_center);
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++) {
+            float dis = (i - y_center) * (i - y_center) + (j - x_center) * (j - x_center);
+            dis = 1 - sqrtf(dis) / dis_max;
+            p[1] = p[2] = p[0] = 0;
+            if (0 == weight_type) p[3] = (uint8_t)(dis * 254.);
+            else p[3] = (uint8_t)(dis * dis * 254);
+            if (p[3] < 2) p[3] = 2;
+            p += 4;
+        }
+}
+
 /* --- 16S instantiation --- */
 #define T int16_t
 #define WT int
@@ -241,7 +316,8 @@ void orc_warp_nearest_const_32f(const float* src, int srows, int scols, int cn,
 typedef struct orc_tile {
     void*  lap[ORC_MAX_LEVELS];
     float* w[ORC_MAX_LEVELS];
-    int    has_pyr;     /* pyr_laplace.size() != 0 */
+    uint8_t* bgra;      /* Map2DCPU mode: ele->img (256x256 8UC4) */
+    int    has_pyr;     /* pyr_laplace.size() != 0 (Map2DCPU mode: !img.empty()) */
     int    changed;
 } orc_tile;
 
@@ -258,6 +334,7 @@ struct orc_map {
     orc_tile** data;                 /* dense row-major, lazily allocated */
     int    off_x, off_y;             /* stable tile coord = dense + off   */
     float* weight_image; int wi_rows, wi_cols;
+    uint8_t* weight_image8;          /* Map2DCPU mode */
     /* test hooks */
     int    keep_last;
     int    last_x0, last_y0, last_tx, last_ty; double last_M[9];
@@ -269,7 +346,7 @@ static size_t elt_size(const orc_map* m) { return m->opt.force_float ? sizeof(fl
 void orc_default_options(orc_options* o)
 {
     o->band_num = 5; o->force_float = 0; o->weight_type = 0; o->high_quality = 1;
-    o->bg_color = 0; o->resolution = 0; o->scale = 1;
+    o->bg_color = 0; o->resolution = 0; o->scale = 1; o->single_band = 0;
 }
 
 orc_map* orc_map_create(const orc_options* o)
@@ -286,6 +363,7 @@ static void free_tile(orc_tile* t)
 {
     if (!t) return;
     for (int i = 0; i < ORC_MAX_LEVELS; i++) { free(t->lap[i]); free(t->w[i]); }
+    free(t->bgra);
     free(t);
 }
 
@@ -303,7 +381,7 @@ static void free_last(orc_map* m)
 void orc_map_destroy(orc_map* m)
 {
     if (!m) return;
-    free_grid(m); free(m->weight_image); free_last(m); free(m);
+    free_grid(m); free(m->weight_image); free(m->weight_image8); free_last(m); free(m);
 }
 
 /* Map2DPrepare::prepare (Map2D.cpp:32-49) + MultiBandMap2DCPUData::prepare
@@ -359,6 +437,7 @@ int orc_map_prepare(orc_map* m, const double plane[7], const double cam[6], int 
     m->w = w; m->h = h; m->off_x = m->off_y = 0;
     m->data = (orc_tile**)calloc((size_t)w * h, sizeof(orc_tile*));
     free(m->weight_image); m->weight_image = NULL; m->wi_rows = m->wi_cols = 0;
+    free(m->weight_image8); m->weight_image8 = NULL;
     m->valid = 1;
     return 1;
 }
@@ -451,6 +530,50 @@ static int render_frame(orc_map* m, const uint8_t* bgr, int rows, int cols, cons
     ymax = m->min[1] + m->ele_size * ymaxInt;
     (void)xmax; (void)ymax;
 
+    if (m->opt.single_band) {
+        /* Map2DCPU::renderFrame, Map2DCPU.cpp:236-334: BGRA source (alpha = weight byte), one 8-bit warp,
+         * select `ele.a < dst.a` */
+        if (!m->weight_image8 || m->wi_cols != cols || m->wi_rows != rows) {
+            free(m->weight_image8);
+            m->weight_image8 = (uint8_t*)malloc((size_t)rows * cols * 4);
+            m->wi_rows = rows; m->wi_cols = cols;
+            orc_weight_image_8uc4(m->weight_image8, rows, cols, m->opt.weight_type);
+        }
+        const size_t n = (size_t)rows * cols;
+        uint8_t* srcb = (uint8_t*)malloc(n * 4);
+        memcpy(srcb, m->weight_image8, n * 4);
+        for (size_t i = 0; i < n; i++) { srcb[4 * i] = bgr[3 * i]; srcb[4 * i + 1] = bgr[3 * i + 1]; srcb[4 * i + 2] = bgr[3 * i + 2]; }
+        const float s4[8] = { 0.f, 0.f, (float)m->cam_w, 0.f, 0.f, (float)m->cam_h, (float)m->cam_w, (float)m->cam_h };
+        float d4[8];
+        for (int i = 0; i < 4; i++) {
+            d4[2 * i]     = (float)((pts[2 * i] - xmin) * m->length_pixel_inv);
+            d4[2 * i + 1] = (float)((pts[2 * i + 1] - ymin) * m->length_pixel_inv);
+        }
+        double Ms[9];
+        orc_get_perspective_transform(s4, d4, Ms);
+        const int txs = xmaxInt - xminInt, tys = ymaxInt - yminInt;
+        const int dr = tys * ORC_ELE_PIXELS, dc = txs * ORC_ELE_PIXELS;
+        uint8_t* dstb = (uint8_t*)malloc((size_t)dr * dc * 4);
+        orc_warp_linear_const_8u(srcb, rows, cols, 4, dstb, dr, dc, Ms);
+        free(srcb);
+        for (int x = xminInt; x < xmaxInt; x++)
+            for (int y = yminInt; y < ymaxInt; y++) {
+                orc_tile* ele = m->data[y * m->w + x];
+                if (!ele) ele = m->data[y * m->w + x] = (orc_tile*)calloc(1, sizeof(orc_tile));
+                if (!ele->bgra) ele->bgra = (uint8_t*)calloc((size_t)ORC_ELE_PIXELS * ORC_ELE_PIXELS, 4);
+                for (int r = 0; r < ORC_ELE_PIXELS; r++) {
+                    const uint8_t* dp = dstb + (((size_t)(y - yminInt) * ORC_ELE_PIXELS + r) * dc + (size_t)(x - xminInt) * ORC_ELE_PIXELS) * 4;
+                    uint8_t* ep = ele->bgra + (size_t)r * ORC_ELE_PIXELS * 4;
+                    for (int c = 0; c < ORC_ELE_PIXELS; c++)
+                        if (ep[4 * c + 3] < dp[4 * c + 3]) memcpy(ep + 4 * c, dp + 4 * c, 4);
+                }
+                ele->has_pyr = 1; ele->changed = 1;
+            }
+        free(dstb);
+        m->last_x0 = xminInt + m->off_x; m->last_y0 = yminInt + m->off_y; m->last_tx = txs; m->last_ty = tys;
+        memcpy(m->last_M, Ms, sizeof(Ms));
+        return 1;
+    }
     /* 3. weight image (built once, cloned per frame: .cpp:396-425) */
     if (!m->weight_image || m->wi_cols != cols || m->wi_rows != rows) {
         free(m->weight_image);
@@ -564,7 +687,17 @@ void orc_map_grid(orc_map* m, int dims[4], double geo[6])
     geo[4] = m->ele_size; geo[5] = m->length_pixel;
 }
 
-int orc_map_num_levels(orc_map* m) { return m->band_num + 1; }
+int orc_map_num_levels(orc_map* m) { return m->opt.single_band ? 1 : m->band_num + 1; }
+
+int orc_map_get_tile_bgra(orc_map* m, int ix, int iy, uint8_t* bgra)
+{
+    const int x = ix - m->off_x, y = iy - m->off_y;
+    if (!m->opt.single_band || x < 0 || y < 0 || x >= m->w || y >= m->h) return 0;
+    orc_tile* t = m->data[y * m->w + x];
+    if (!t || !t->bgra) return 0;
+    memcpy(bgra, t->bgra, (size_t)ORC_ELE_PIXELS * ORC_ELE_PIXELS * 4);
+    return 1;
+}
 
 static orc_tile* tile_at(orc_map* m, int ix, int iy)
 {

@@ -17,7 +17,7 @@ ELE = 256
 class Options(C.Structure):
     _fields_ = [("band_num", C.c_int), ("force_float", C.c_int), ("weight_type", C.c_int),
                 ("high_quality", C.c_int), ("bg_color", C.c_int),
-                ("resolution", C.c_double), ("scale", C.c_double)]
+                ("resolution", C.c_double), ("scale", C.c_double), ("single_band", C.c_int)]
 
 
 def build():
@@ -47,6 +47,7 @@ def lib():
     L.orc_map_tile_count.argtypes = [vp]
     L.orc_map_tile_coords.argtypes = [vp, ip, C.c_int]
     L.orc_map_get_tile_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.orc_map_get_tile_bgra.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orc_map_blend_tile_raw.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orc_map_blend_tile.argtypes = [vp, C.c_int, C.c_int, vp]
     L.orc_map_save_size.argtypes = [vp, ip, ip, ip, ip]
@@ -130,6 +131,20 @@ def warp_nearest_const(src, M0, drows, dcols):
     return d
 
 
+def warp_linear_const_8u(src, M0, drows, dcols):
+    s = _img(src, np.uint8); cn = s.shape[2]
+    d = np.empty((drows, dcols, cn), np.uint8)
+    M0, pm = _d(np.asarray(M0).reshape(9))
+    lib().orc_warp_linear_const_8u(s.ctypes.data_as(C.c_void_p), s.shape[0], s.shape[1], cn, d.ctypes.data_as(C.c_void_p), drows, dcols, pm)
+    return d
+
+
+def weight_image_8uc4(rows, cols, weight_type=0):
+    w = np.empty((rows, cols, 4), np.uint8)
+    lib().orc_weight_image_8uc4(w.ctypes.data_as(C.c_void_p), rows, cols, weight_type)
+    return w
+
+
 def pyr_down(src):
     dt = np.int16 if src.dtype == np.int16 else np.float32
     s = _img(src, dt); cn = s.shape[2]
@@ -183,8 +198,8 @@ class OracleMap:
     """MultiBandMap2DCPU restated (thread=false)."""
 
     def __init__(self, band_num=5, force_float=0, weight_type=0, high_quality=1, bg_color=0,
-                 resolution=0.0, scale=1.0):
-        self.opt = Options(band_num, force_float, weight_type, high_quality, bg_color, resolution, scale)
+                 resolution=0.0, scale=1.0, single_band=0):
+        self.opt = Options(band_num, force_float, weight_type, high_quality, bg_color, resolution, scale, single_band)
         self.h = lib().orc_map_create(C.byref(self.opt))
         self.force_float = force_float
         self.dtype = np.float32 if force_float else np.int16
@@ -229,6 +244,10 @@ class OracleMap:
         ok = lib().orc_map_get_tile_level(self.h, ix, iy, level, lap.ctypes.data_as(C.c_void_p),
                                           w.ctypes.data_as(C.c_void_p))
         return (lap, w) if ok else None
+
+    def tile_bgra(self, ix, iy):
+        out = np.empty((ELE, ELE, 4), np.uint8)
+        return out if lib().orc_map_get_tile_bgra(self.h, ix, iy, out.ctypes.data_as(C.c_void_p)) else None
 
     def blend_tile_raw(self, ix, iy):
         out = np.empty((ELE, ELE, 3), self.dtype)

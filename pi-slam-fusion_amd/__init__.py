@@ -77,6 +77,7 @@ def lib():
     L.pf_tile_count.argtypes = [vp]
     L.pf_tile_coords.argtypes = [vp, ip, C.c_int]
     L.pf_get_tile_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.pf_get_tile_bgra.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_tile_raw.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_tile.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_changed.argtypes = [vp, ip, vp, C.c_int]
@@ -247,6 +248,10 @@ class Map2D:
         lap = np.empty((s, s, 3), self.dtype); w = np.empty((s, s), np.float32)
         ok = lib().pf_get_tile_level(self._h, ix, iy, level, lap.ctypes.data, w.ctypes.data)
         return (lap, w) if ok else None
+
+    def tile_bgra(self, ix, iy):
+        out = np.empty((ELE_PIXELS, ELE_PIXELS, 4), np.uint8)
+        return out if lib().pf_get_tile_bgra(self._h, ix, iy, out.ctypes.data) else None
 
     def blend_tile_raw(self, ix, iy):
         out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), self.dtype)

@@ -68,6 +68,7 @@ int pf_grid(pf_map* m, int dims[4], double geo[6]) { return m && m->impl.grid(di
 int pf_tile_count(pf_map* m) { return m ? m->impl.tile_count() : 0; }
 int pf_tile_coords(pf_map* m, int* xy, int cap) { return m ? m->impl.tile_coords(xy, cap) : 0; }
 int pf_get_tile_level(pf_map* m, int ix, int iy, int level, void* lap, float* w) { return m && m->impl.get_tile_level(ix, iy, level, lap, w); }
+int pf_get_tile_bgra(pf_map* m, int ix, int iy, uint8_t* bgra) { return m && bgra && m->impl.get_tile_bgra(ix, iy, bgra); }
 int pf_blend_tile_raw(pf_map* m, int ix, int iy, void* out) { return m && out && m->impl.blend_tile(ix, iy, out, nullptr, nullptr); }
 int pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr) { return m && bgr && m->impl.blend_tile(ix, iy, nullptr, bgr, nullptr); }
 int pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap) { return (m && xy && bgr && cap > 0) ? m->impl.blend_changed(xy, bgr, cap) : 0; }

@@ -75,12 +75,16 @@ bool DevBuf::reserve(size_t bytes)
 void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 // ------------------------------------------------------------------ setup
-FusionMap::FusionMap(int /*type*/, bool thread, const pf_options& opt) : opt_(opt), thread_(thread)
+FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), thread_(thread)
 {
+    // Map2D::create: TypeCPU -> Map2DCPU; TypeGPU falls back to Map2DCPU in the reference (Map2D.cpp:58-65)
+    single_band_ = (type == PF_TYPE_CPU || type == PF_TYPE_GPU);
     const int lim = (int)std::ceil(std::log((double)kElePixels) / std::log(2.0));      // .cpp:263
     band_num_ = std::min(opt_.band_number, lim);
     if (band_num_ < 0) band_num_ = 0;
+    if (single_band_) band_num_ = 0;
     lay_ = make_layout(band_num_, opt_.force_float != 0);
+    if (single_band_) { lay_.f32 = 0; lay_.lap_off[0] = 0; lay_.w_off[0] = 0; lay_.slot_bytes = kElePixels * kElePixels * 4; }
     store_.configure(lay_.slot_bytes);
     if (opt_.max_queue <= 0) opt_.max_queue = 20;
     if (opt_.shard_count < 1) opt_.shard_count = 1;
@@ -128,7 +132,7 @@ FusionMap::~FusionMap()
         if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
     }
     for (int i = 0; i < kMaxLevels; i++) { g_[i].release(); wgt_[i].release(); blend_lv_[i].release(); }
-    blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release();
+    blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release();
     store_.clear();
     (void)hipStreamDestroy(stream_);
     (void)hipStreamDestroy(copy_stream_);
@@ -515,6 +519,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     bool grow = false;
     for (int i = 0; i <= L; i++) {
         const size_t n = (size_t)(crows >> i) * (ccols >> i);
+        if (single_band_) continue;
         if (fused) { if (i >= 1 && i < L && (gw_[i].cap < n * pxb || gw2_[i].cap < n * pxb)) grow = true; }
         else if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
     }
@@ -523,6 +528,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         HIP_OK(sync_all());
         for (int i = 0; i <= L; i++) {
             const size_t n = (size_t)(crows >> i) * (ccols >> i);
+            if (single_band_) continue;
             if (fused) { if (i >= 1 && i < L && (!gw_[i].reserve(n * pxb) || !gw2_[i].reserve(n * pxb))) return false; }
             else if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
         }
@@ -569,7 +575,20 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     a.dis_max = std::sqrt(a.xc * a.xc + a.yc * a.yc);
     a.weight_type = opt_.weight_type;
     a.src_cn = f.cn == 4 ? 4 : 3;
-    if (fused) {
+    if (single_band_) {
+        // Map2DCPU::renderFrame (Map2DCPU.cpp:236-334): per-pixel work only, so a shard needs no halo
+        if (w8_rows_ != f.rows || w8_cols_ != f.cols) {
+            HIP_OK(sync_all());
+            if (!w8_.reserve((size_t)f.rows * f.cols)) return false;
+            launch_weight8(stream_, (uint8_t*)w8_.p, f.rows, f.cols, opt_.weight_type);
+            w8_rows_ = f.rows; w8_cols_ = f.cols;
+        }
+        a.y_off = by0 * kElePixels; a.x_off = bx0 * kElePixels;
+        a.wrows = (by1 - by0) * kElePixels; a.wcols = (bx1 - bx0) * kElePixels;
+        prof_begin(K_SINGLE, (double)a.src_cn * f.rows * f.cols + (double)a.wrows * a.wcols * 8);
+        launch_single(stream_, src, (const uint8_t*)w8_.p, a, dtab, tx);
+        prof_end();
+    } else if (fused) {
         // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
         struct Win C[kMaxLevels];
@@ -678,10 +697,21 @@ int FusionMap::tile_coords(int* xy, int cap)
     return (int)v.size();
 }
 
+bool FusionMap::get_tile_bgra(int ix, int iy, uint8_t* bgra)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !single_band_ || !set_device()) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh) return false;
+    HIP_OK(sync_all());
+    HIP_OK(hipMemcpy(bgra, t->base, (size_t)kElePixels * kElePixels * 4, hipMemcpyDeviceToHost));
+    return true;
+}
+
 bool FusionMap::get_tile_level(int ix, int iy, int level, void* lap, float* w)
 {
     std::lock_guard<std::mutex> l(mu_);
-    if (!init_ok_ || !set_device()) return false;
+    if (!init_ok_ || single_band_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh || level < 0 || level > band_num_) return false;
     HIP_OK(sync_all());
@@ -796,6 +826,13 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
 
 bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo)
 {
+    if (single_band_) {          // the Map2DCPU tile is displayable as is (glTexImage2D GL_BGRA, Map2DCPU.cpp:497-503)
+        std::vector<uint8_t> px((size_t)kElePixels * kElePixels * 4);
+        if (!get_tile_bgra(ix, iy, px.data())) return false;
+        if (raw) std::memcpy(raw, px.data(), px.size());
+        if (bgr) for (size_t i = 0; i < (size_t)kElePixels * kElePixels; i++) { bgr[3 * i] = px[4 * i]; bgr[3 * i + 1] = px[4 * i + 1]; bgr[3 * i + 2] = px[4 * i + 2]; }
+        return true;
+    }
     std::lock_guard<std::mutex> l(mu_);
     if (!init_ok_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
@@ -818,6 +855,19 @@ int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
     if (tiles.empty()) return 0;
     // bound the scratch: 64 tiles per batch
     const size_t tile_px = (size_t)kElePixels * kElePixels * 3;
+    if (single_band_) {
+        if (sync_all() != hipSuccess) return 0;
+        std::vector<uint8_t> px((size_t)kElePixels * kElePixels * 4);
+        for (size_t i = 0; i < tiles.size(); i++) {
+            Tile* t = store_.find(tiles[i].first, tiles[i].second);
+            if (hipMemcpy(px.data(), t->base, px.size(), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+            uint8_t* d = bgr + i * tile_px;
+            for (size_t k = 0; k < (size_t)kElePixels * kElePixels; k++) { d[3 * k] = px[4 * k]; d[3 * k + 1] = px[4 * k + 1]; d[3 * k + 2] = px[4 * k + 2]; }
+            xy[2 * i] = tiles[i].first; xy[2 * i + 1] = tiles[i].second;
+            t->changed = false;
+        }
+        return (int)tiles.size();
+    }
     for (size_t o = 0; o < tiles.size(); o += 64) {
         std::vector<std::pair<int, int>> part(tiles.begin() + o, tiles.begin() + std::min(tiles.size(), o + 64));
         if (!blend_batch(part, nullptr, nullptr, bgr + o * tile_px)) return 0;
@@ -846,6 +896,22 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     const int wx = mxx + 1 - mnx, wy = mxy + 1 - mny;
     *rows = wy * kElePixels; *cols = wx * kElePixels; *tx0 = mnx; *ty0 = mny;
     if (!bgr) return true;
+    if (single_band_) {          // Map2DCPU::save (Map2DCPU.cpp:523-563): paste the tiles; holes are zero here
+        HIP_OK(sync_all());
+        std::memset(bgr, 0, (size_t)*rows * *cols * 3);
+        std::vector<uint8_t> px((size_t)kElePixels * kElePixels * 4);
+        bool ok = true;
+        store_.for_each([&](int ix, int iy, Tile& t) {
+            if (t.fresh || !ok) return;
+            if (hipMemcpy(px.data(), t.base, px.size(), hipMemcpyDeviceToHost) != hipSuccess) { ok = false; return; }
+            for (int r = 0; r < kElePixels; r++) {
+                uint8_t* d = bgr + (((size_t)(iy - mny) * kElePixels + r) * *cols + (size_t)(ix - mnx) * kElePixels) * 3;
+                const uint8_t* sp = px.data() + (size_t)r * kElePixels * 4;
+                for (int c = 0; c < kElePixels; c++) { d[3 * c] = sp[4 * c]; d[3 * c + 1] = sp[4 * c + 1]; d[3 * c + 2] = sp[4 * c + 2]; }
+            }
+        });
+        return ok;
+    }
     const int L = band_num_;
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     std::vector<uint64_t> tab((size_t)wx * wy, 0);

@@ -82,11 +82,12 @@ public:
     bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
 
     int  num_levels() const { return band_num_ + 1; }
-    int  pyramid_type() const { return lay_.f32 ? PF_32FC3 : PF_16SC3; }
+    int  pyramid_type() const { return single_band_ ? PF_8UC4 : (lay_.f32 ? PF_32FC3 : PF_16SC3); }
     bool grid(int dims[4], double geo[6]);
     int  tile_count();
     int  tile_coords(int* xy, int cap);
     bool get_tile_level(int ix, int iy, int level, void* lap, float* w);
+    bool get_tile_bgra(int ix, int iy, uint8_t* bgra);
     bool blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo);
     int  blend_changed(int* xy, uint8_t* bgr, int cap);
     size_t halo_bytes_for(int dx, int dy) const { return halo_bytes(lay_, dx, dy); }
@@ -118,6 +119,8 @@ private:
     int        band_num_ = 5;
     TileLayout lay_{};
     bool       thread_ = false, init_ok_ = false;
+    bool       single_band_ = false;      // Map2DCPU semantics (TypeCPU / TypeGPU), one BGRA tile per cell
+    DevBuf     w8_; int w8_rows_ = 0, w8_cols_ = 0;   // its weight byte plane
     int        device_ = 0;
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
 

@@ -1082,7 +1082,7 @@ TileLayout make_layout(int band_num, bool f32)
 const char* kernel_name(int id)
 {
     static const char* n[K_COUNT] = { "warp", "pyrdown_img", "pyrdown_w", "lap_select", "blend_gather", "collapse",
-                                      "blend_finish", "mosaic_gather", "save_finish", "level0_fused", "level_fused" };
+                                      "blend_finish", "mosaic_gather", "save_finish", "level0_fused", "level_fused", "single_band" };
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
 }
 

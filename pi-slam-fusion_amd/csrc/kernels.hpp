@@ -49,7 +49,7 @@ struct BlendSrc {
 
 // kernel ids for the profile table
 enum KernelId { K_WARP = 0, K_PYRDOWN_IMG, K_PYRDOWN_W, K_LAP_SELECT, K_BLEND_GATHER, K_COLLAPSE,
-                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_LEVEL0, K_LEVEL, K_COUNT };
+                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_LEVEL0, K_LEVEL, K_SINGLE, K_COUNT };
 const char* kernel_name(int id);
 
 void launch_warp(hipStream_t s, bool f32, const uint8_t* src, const WarpArgs& a, void* g0, float* w0);
@@ -89,5 +89,9 @@ void launch_save_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, 
 // halo strip pack (multi-GPU blend): writes the strip set a neighbour at (dx,dy) needs
 size_t halo_bytes(const TileLayout& lay, int dx, int dy);
 void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, int dx, int dy, void* out);
+
+// Map2DCPU semantics (single_band.hip): weight byte plane, BGRA warp + select into 256x256x4 tiles
+void launch_weight8(hipStream_t s, uint8_t* w, int rows, int cols, int weight_type);
+void launch_single(hipStream_t s, const uint8_t* src, const uint8_t* w8, const WarpArgs& a, const uint64_t* table, int tiles_x);
 
 }  // namespace pf

@@ -1,0 +1,104 @@
+"""Row f2 of SURVEY 8: Map2DCPU semantics (single 8-bit band, alpha-byte weights) -- the
+`Map2D::create(TypeCPU)` / `TypeGPU` object of the reference (Map2DFusion/Map2DCPU.cpp:150-334),
+against the oracle's restatement of it.  Bit-exact byte work."""
+import numpy as np
+import pytest
+
+from helpers import jitter_poses, workloads
+
+
+# ---------------------------------------------------------------- oracle pins (CPU)
+def test_weight_byte_image(orc):
+    w = orc.weight_image_8uc4(480, 640, 0)
+    assert (w[..., :3] == 0).all() and w[240, 320, 3] == 254 and w[0, 0, 3] == 2      # dis*254 truncated, floor 2
+    xc, yc = np.float32(320), np.float32(240)
+    i, j = np.mgrid[0:480, 0:640].astype(np.float32)
+    dis = np.float32(1) - np.sqrt((i - yc) * (i - yc) + (j - xc) * (j - xc), dtype=np.float32) / np.sqrt(xc * xc + yc * yc, dtype=np.float32)
+    a = np.maximum((dis.astype(np.float64) * 254.0).astype(np.uint8), 2)
+    assert np.array_equal(w[..., 3], a)
+    w1 = orc.weight_image_8uc4(9, 7, 1)
+    assert w1[..., 3].min() == 2
+
+
+def test_fixed_point_warp_known_answers(orc):
+    rng = np.random.RandomState(1)
+    src = rng.randint(0, 256, (12, 16, 4)).astype(np.uint8)
+    assert np.array_equal(orc.warp_linear_const_8u(src, np.eye(3), 12, 16), src)
+    T = np.array([[1, 0, 2], [0, 1, 1], [0, 0, 1.0]])
+    out = orc.warp_linear_const_8u(src, T, 14, 20)
+    assert np.array_equal(out[1:13, 2:18], src) and (out[0] == 0).all() and (out[:, :2] == 0).all()     # CONSTANT 0 outside
+    H = np.array([[1, 0, 0.5], [0, 1, 0], [0, 0, 1.0]])                                                     # half pixel
+    row = np.array([[[10], [20], [40], [41]]], np.uint8).repeat(3, axis=0)
+    o = orc.warp_linear_const_8u(row, H, 3, 5)[1, :, 0]
+    # taps 16384/16384, (a*16384 + b*16384 + 16384) >> 15; left of the image one tap is the constant 0
+    assert list(o) == [(0 + 10 * 16384 + 16384) >> 15, (10 * 16384 + 20 * 16384 + 16384) >> 15,
+                       (20 * 16384 + 40 * 16384 + 16384) >> 15, (40 * 16384 + 41 * 16384 + 16384) >> 15,
+                       (41 * 16384 + 16384) >> 15]
+
+
+# ---------------------------------------------------------------- GPU parity
+def run_pair(pf, orc, cam, poses, frames, typ, n_prepare=None, **opt):
+    wl = workloads()
+    g = pf.Map2D.create(typ, False, **opt)
+    o = orc.OracleMap(single_band=1, weight_type=opt.get("weight_type", 0), scale=opt.get("scale", 1.0))
+    prep = poses[:n_prepare] if n_prepare else poses
+    assert g.prepare(wl.IDENTITY_PLANE, cam, prep) and o.prepare(wl.IDENTITY_PLANE, cam, prep)
+    for f, p in zip(frames, poses):
+        assert g.feed(f, p) == o.feed(f[:, :, :3], p)
+    g.sync()
+    assert g.grid() == o.grid() and g.tiles() == o.tiles() and len(o.tiles()) > 0
+    return g, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("typ", ["TypeCPU", "TypeGPU"])
+@pytest.mark.parametrize("weight_type", [0, 1])
+def test_single_band_against_oracle(pf, orc, typ, weight_type):
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(9, seed=19 + weight_type)
+    frames = [wl.noise_frame(480, 640, 40 + k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, getattr(pf, typ), n_prepare=2, weight_type=weight_type)
+    for t in o.tiles():
+        assert np.array_equal(g.tile_bgra(*t), o.tile_bgra(*t)), t
+    assert g.num_levels == 1
+    t = o.tiles()[len(o.tiles()) // 2]
+    assert np.array_equal(g.blend_tile(*t), o.tile_bgra(*t)[:, :, :3])
+    changed, imgs = g.blend_changed()
+    assert sorted(changed) == sorted(o.tiles()) and g.blend_changed()[0] == []
+    img, org = g.save_to_memory()
+    x0, y0 = org
+    for (ix, iy) in o.tiles():
+        assert np.array_equal(img[(iy - y0) * 256:(iy - y0 + 1) * 256, (ix - x0) * 256:(ix - x0 + 1) * 256], o.tile_bgra(ix, iy)[:, :, :3])
+
+
+@pytest.mark.gpu
+def test_single_band_bgra_input_above_plane_scale(pf, orc):
+    wl = workloads()
+    cam = [320, 240, 260, 250, 158.5, 121.25]
+    poses = jitter_poses(6, seed=5, step=(11.0, 5.0), height=60.0, below=False)
+    frames = [np.concatenate([wl.noise_frame(240, 320, k), wl.noise_frame(240, 320, 77 + k)[:, :, :1]], axis=2) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, pf.TypeCPU, scale=0.5)
+    for t in o.tiles():
+        assert np.array_equal(g.tile_bgra(*t), o.tile_bgra(*t)), t
+
+
+@pytest.mark.gpu
+def test_single_band_shards(pf):
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(6, seed=23, step=(30.0, 25.0))
+    frames = [wl.smooth_frame(480, 640, k) for k in range(len(poses))]
+    maps = []
+    for n, r in ((1, 0), (2, 0), (2, 1)):
+        m = pf.Map2D.create(pf.TypeCPU, False, shard_count=n, shard_rank=r, shard_block=1)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses)
+        for f, p in zip(frames, poses):
+            assert m.feed(f, p)
+        m.sync(); maps.append(m)
+    ref, a, b = maps
+    got = {t: a.tile_bgra(*t) for t in a.tiles()}
+    got.update({t: b.tile_bgra(*t) for t in b.tiles()})
+    assert sorted(got) == sorted(ref.tiles()) and len(a.tiles()) and len(b.tiles())
+    for t in ref.tiles():
+        assert np.array_equal(got[t], ref.tile_bgra(*t))
