@@ -108,3 +108,23 @@ def test_live_wire_cfg4(pf, tmp_path):
         img, p = d.load(k); assert s.feed(img, p)
     s.sync()
     assert map_digest(m) == map_digest(s)
+
+
+def test_overlay_message_format(pf):
+    """Row f4: Map2DUpdate message (MultiBandMap2DCPU.cpp:744-757), GPS maths of utils_GPS.cpp:133-160."""
+    ov = importlib.import_module("pi_slam_fusion_amd.overlay")
+    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 0.0, 0.0)
+    assert (lng, lat) == (108.888931, 34.257287)
+    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 92.0, 0.0)      # ~92 m per 0.001 deg of longitude at 34 N
+    assert abs(lng - 108.889931) < 2e-5 and lat == 34.257287
+    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 0.0, 110.9)     # ~110.9 m per 0.001 deg of latitude
+    assert abs(lat - 34.258287) < 2e-5
+
+    class FakeMap:
+        def grid(self):
+            return [10, 8, -2, -1], [-100.0, -50.0, 412.0, 359.6, 51.2, 0.2]
+    s = ov.tile_overlay_command(pf, FakeMap(), [0, 0, 0, 0, 0, 0, 1], [108.888931, 34.257287, 400.0], 0, 1)
+    parts = s.split()
+    assert parts[:2] == ["Map2DUpdate", "LastTexMat"] and len(parts) == 8 and parts[4] == "0.000000000"
+    x0 = -100.0 + 2 * 51.2
+    assert abs(float(parts[2]) - ov.lnglat_from_distance(108.888931, 34.257287, x0, 0)[0]) < 1e-9
