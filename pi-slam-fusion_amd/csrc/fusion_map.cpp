@@ -132,7 +132,7 @@ FusionMap::~FusionMap()
         if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
     }
     for (int i = 0; i < kMaxLevels; i++) { g_[i].release(); wgt_[i].release(); blend_lv_[i].release(); }
-    blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release();
+    blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release(); wmap_.release();
     store_.clear();
     (void)hipStreamDestroy(stream_);
     (void)hipStreamDestroy(copy_stream_);
@@ -589,6 +589,17 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         launch_single(stream_, src, (const uint8_t*)w8_.p, a, dtab, tx);
         prof_end();
     } else if (fused) {
+        // weightImage (MultiBandMap2DCPU.cpp:396-425): built once per frame size, gathered by the warp
+        static const bool no_wmap = std::getenv("PF_NO_WMAP") != nullptr;      // diagnostics: analytic weight per pixel
+        if (!no_wmap) {
+            if (wmap_rows_ != f.rows || wmap_cols_ != f.cols) {
+                HIP_OK(sync_all());
+                if (!wmap_.reserve((size_t)f.rows * f.cols * 4)) return false;
+                launch_weight32(stream_, (float*)wmap_.p, f.rows, f.cols, opt_.weight_type);
+                wmap_rows_ = f.rows; wmap_cols_ = f.cols;
+            }
+            a.wmap = (const float*)wmap_.p;
+        }
         // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
         struct Win C[kMaxLevels];

@@ -121,6 +121,7 @@ private:
     bool       thread_ = false, init_ok_ = false;
     bool       single_band_ = false;      // Map2DCPU semantics (TypeCPU / TypeGPU), one BGRA tile per cell
     DevBuf     w8_; int w8_rows_ = 0, w8_cols_ = 0;   // its weight byte plane
+    DevBuf     wmap_; int wmap_rows_ = 0, wmap_cols_ = 0;   // multi-band: fp32 weight plane (weightImage)
     int        device_ = 0;
     hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
 

@@ -345,11 +345,13 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         float wv = 0.f;
         if (abl & 8) wv = (float)(sx + sy); else
         if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
+            if (a.wmap) wv = a.wmap[__mul24(sy, a.scols) + sx]; else {
             const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
             float dis = dy * dy + dx * dx;
             dis = 1.f - sqrtf(dis) / a.dis_max;
             wv = a.weight_type == 0 ? dis : dis * dis;
             if (wv <= 1e-5f) wv = 1e-5f;          // == ((double)wv <= 1e-5): 1e-5f is the largest float below 1e-5
+            }
         }
         o.w = wv;
     }

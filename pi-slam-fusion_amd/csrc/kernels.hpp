@@ -38,6 +38,7 @@ struct WarpArgs {
     int    wrows, wcols;    // window extent (multiple of 4 rows / 64 cols)
     float  xc, yc, dis_max; // radial weight constants (MultiBandMap2DCPU.cpp:404-406)
     int    weight_type;
+    const float* wmap;      // optional h x w radial weight plane (same values as the analytic form); nullptr = recompute
     int    src_cn;          // 3 = BGR8, 4 = BGRA8 (alpha ignored: the tracker's cvtColor BGRA2BGR, TrackerOpt.cpp:376-380, done in the gather)
 };
 
@@ -92,6 +93,8 @@ void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, in
 
 // Map2DCPU semantics (single_band.hip): weight byte plane, BGRA warp + select into 256x256x4 tiles
 void launch_weight8(hipStream_t s, uint8_t* w, int rows, int cols, int weight_type);
+// the reference's CV_32FC1 weightImage (MultiBandMap2DCPU.cpp:400-418), built once per frame size
+void launch_weight32(hipStream_t s, float* w, int rows, int cols, int weight_type);
 void launch_single(hipStream_t s, const uint8_t* src, const uint8_t* w8, const WarpArgs& a, const uint64_t* table, int tiles_x);
 
 }  // namespace pf

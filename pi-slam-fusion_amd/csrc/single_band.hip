@@ -31,6 +31,29 @@ void launch_weight8(hipStream_t s, uint8_t* w, int rows, int cols, int weight_ty
     hipLaunchKernelGGL(k_weight8, grid, block, 0, s, w, rows, cols, xc, yc, dis_max, weight_type);
 }
 
+// MultiBandMap2DCPU's weightImage (MultiBandMap2DCPU.cpp:400-418): same float expression as the
+// in-kernel analytic weight, evaluated once per frame size instead of once per warped pixel
+__global__ __launch_bounds__(256) void k_weight32(float* __restrict__ w, int rows, int cols, float xc, float yc,
+                                                   float dis_max, int weight_type)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= cols) return;
+    const float dy = (float)i - yc, dx = (float)j - xc;
+    float dis = dy * dy + dx * dx;
+    dis = 1.f - sqrtf(dis) / dis_max;
+    float wv = weight_type == 0 ? dis : dis * dis;
+    if (wv <= 1e-5f) wv = 1e-5f;
+    w[(long)i * cols + j] = wv;
+}
+
+void launch_weight32(hipStream_t s, float* w, int rows, int cols, int weight_type)
+{
+    const float xc = (float)(cols / 2), yc = (float)(rows / 2);
+    const float dis_max = sqrtf(xc * xc + yc * yc);
+    dim3 grid((cols + 255) / 256, rows), block(256);
+    hipLaunchKernelGGL(k_weight32, grid, block, 0, s, w, rows, cols, xc, yc, dis_max, weight_type);
+}
+
 __device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
 // one thread = one canvas pixel; a wave = one 64-pixel OpenCV coordinate block row
