@@ -467,7 +467,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // arrays of this struct end up in scratch), four loads in flight per thread before their LDS stores.
 template <bool F32, int LAH, int LNT>
 __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, const PxT<F32>* __restrict__ gin,
-                                               int ax0, int ay0, int rows, int cols, int tid)
+                                               int ax0, int ay0, int rows, int cols, int tid, int begin = 0)
 {
     using Px = PxT<F32>;
     auto gaddr = [&](int idx) {
@@ -478,7 +478,8 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
     };
 #pragma unroll
     for (int base = 0; base < LAH * LAW; base += 4 * LNT) {
-        const int i0 = base + tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT;
+        if (base + begin >= LAH * LAW) break;
+        const int i0 = base + begin + tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT;
         const Px t0 = gin[gaddr(i0)], t1 = gin[gaddr(i1)], t2 = gin[gaddr(i2)], t3 = gin[gaddr(i3)];
         if (i0 < LAH * LAW) Aflat[i0] = t0;
         if (i1 < LAH * LAW) Aflat[i1] = t1;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
     }
 }
 
-template <bool F32, bool FROM_WARP, int LBH, int LNT>
+template <bool F32, bool FROM_WARP, int LBH, int LNT, int LS>
 __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
                                                 const uint64_t* __restrict__ table)
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
     using Px = PxT<F32>; using Hx = HxT<F32>;
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
     static_assert((LBH * LBW) % LNT == 0, "D stage: whole passes");
+    static_assert(LS == 1 || 7 * LAW <= LNT, "strip shift: one overlap pixel per thread");
     __shared__ Px A[LAH][LAW];
     __shared__ Hx Ht[LAH][LQW];
     __shared__ Px Bt[LQH][LQW];
@@ -509,11 +511,17 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
     }
     const int bx = b % g.nbx, by = b / g.nbx;
-    const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
-    const int ax0 = x0 - 4, ay0 = y0 - 4;
+    const int x0 = g.cx0 + bx * LBW, ax0 = x0 - 4, bx0 = (x0 >> 1) - 1;
     const int nrows = g.rows >> 1, ncols = g.cols >> 1;         // level i+1 extent
-    const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
     const int tid = threadIdx.x;
+    // Rolling vertical strip: the workgroup walks LS consecutive LBH-row blocks; the 7 halo rows two
+    // consecutive blocks share stay in LDS (shifted to the top), so only LBH new rows are staged per step.
+#pragma unroll 1
+    for (int st = 0; st < LS; st++) {
+    const int y0 = g.cy0 + (by * LS + st) * LBH;
+    if (y0 >= g.cy1 || y0 >= g.rows) break;
+    const int ay0 = y0 - 4, by0 = (y0 >> 1) - 1;
+    const int rb = st == 0 ? 0 : 7;                             // first staged row of this step
 
     // tile-table entries of this thread's D pixels: loaded now, used after stage A
     constexpr int ND = LBH * LBW / LNT;
@@ -531,8 +539,8 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
     if constexpr (FROM_WARP) {
         // blocks whose halo lies inside the canvas (all but the rim) skip the REFLECT_101 mapping
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
-        int r = tid / LAW, c = tid - r * LAW;
-        for (int idx = tid; idx < LAH * LAW; idx += LNT) {
+        int r = rb + tid / LAW, c = tid % LAW;
+        for (int idx = rb * LAW + tid; idx < LAH * LAW; idx += LNT) {
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
             if (c >= LAW) { c -= LAW; r++; }
         }
     } else {
-        stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
+        stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid, rb * LAW);
     }
     lds_barrier();
     if (g.ablate & 2) return;
@@ -661,6 +669,15 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         dl[0] = out[0]; dl[1] = out[1]; dl[2] = out[2];
         ((float PF_GLOBAL*)(slot + lay.w_off[g.level]))[loc] = gpx.w;
     }
+    if (st + 1 < LS) {
+        lds_barrier();                                           // every read of A / U of this step is done
+        Px keep;
+        const bool mv = tid < 7 * LAW;
+        if (mv) keep = (&A[0][0])[LBH * LAW + tid];             // rows LBH .. LBH+6 are the next step's rows 0 .. 6
+        lds_barrier();
+        if (mv) (&A[0][0])[tid] = keep;
+    }
+    }   // strip step
 }
 
 // --------------------------------------------------------------------------
@@ -856,16 +873,17 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const bool use4 = force == 4 || (force != 3 && lay.f32);
     const int BH = use4 ? 16 : 32;
-    g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + BH - 1) / BH;
+    const int LSTEPS = 1;     // rolling strips (k_level<..., LS>1>) measured slower on MI355X: kept at one block per workgroup
+    g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + BH * LSTEPS - 1) / (BH * LSTEPS);
     g.ablate = ablate;
     if (g.nbx <= 0 || g.nby <= 0) return;
     dim3 grid(g.nbx * g.nby);
     WarpArgs w{};
     if (wa) w = *wa;
-#define PF_LAUNCH(K, F, W, H, NT) hipLaunchKernelGGL((K<F, W, H, NT>), grid, dim3(NT), 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
+#define PF_LAUNCH(K, F, W, ...) hipLaunchKernelGGL((K<F, W, __VA_ARGS__>), grid, dim3(512), 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
     if (use4) {
-        if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true, 16, 512); else PF_LAUNCH(k_level, true, false, 16, 512); }
-        else         { if (wa) PF_LAUNCH(k_level, false, true, 16, 512); else PF_LAUNCH(k_level, false, false, 16, 512); }
+        if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true, 16, 512, 1); else PF_LAUNCH(k_level, true, false, 16, 512, 1); }
+        else         { if (wa) PF_LAUNCH(k_level, false, true, 16, 512, 1); else PF_LAUNCH(k_level, false, false, 16, 512, 1); }
     } else {
         if (lay.f32) { if (wa) PF_LAUNCH(k_level3, true, true, 32, 512); else PF_LAUNCH(k_level3, true, false, 32, 512); }
         else         { if (wa) PF_LAUNCH(k_level3, false, true, 32, 512); else PF_LAUNCH(k_level3, false, false, 32, 512); }
