@@ -23,7 +23,7 @@ SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_py
 
 
 def short(name):
-    m = re.search(r"k_level<(\w+), (\w+)>", name)
+    m = re.search(r"k_level3?<(\w+), (\w+)", name)
     if m:
         return "level0_fused" if m.group(2) == "true" else "level_fused"
     for k, s in SHORT:
