@@ -207,3 +207,16 @@ def test_full_size_properties(pf):
         assert (w > 0).all()
         assert (lap == (77 if lv == g.num_levels - 1 else 0)).all()
     assert (g.blend_tile(cx, cy) == 77).all()
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_stress_geometry_8000x6000_7band(pf, orc, force_float):
+    """BASELINE.json configs[4] geometry: one 8000x6000 frame, 7-band blend (pyramid levels down to
+    2x2 per tile, SSE-tail rule active on the upper levels), against the oracle."""
+    wl = workloads()
+    cam = [8000, 6000, 6000, 6000, 4000, 3000]
+    poses = wl.serpentine(cam, 100.0, 2, seed=7)
+    frame = wl.noise_frame(6000, 8000, 5)
+    g, o = run_pair(pf, orc, cam, poses[:1], [frame], force_float=force_float, band_number=7)
+    assert g.num_levels == 8 and len(o.tiles()) >= 800
+    assert compare_maps(g, o) == []
