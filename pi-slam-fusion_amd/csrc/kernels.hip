@@ -340,8 +340,23 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     // bit for bit (32/W == 32*(1/W) and scaling by a power of two commutes with rounding).
     // v_cvt_i32_f64 saturates, which is exactly clamp-to-int-range followed by cvRound.
     const double pxn = xn * Wn, pyn = yn * Wn;
+    // cvRound of the four coordinates.  When the whole wave is far inside the int range (always, short of a
+    // degenerate homography) round-half-even comes from one fp64 add of 1.5*2^52 whose low dword IS the
+    // integer -- instead of v_rndne_f64 + v_cvt_i32_f64 per coordinate.
+    int Xn, Yn, X, Y;
+    const bool tame = fabs(pxn) < 3.0e7 && fabs(pyn) < 3.0e7;
+    if (__builtin_amdgcn_ballot_w64(!tame) == 0) {
+        constexpr double kMagic = 6755399441055744.0;
+        Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
+        Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
+        X  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn * 32. + kMagic);
+        Y  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn * 32. + kMagic);
+    } else {
+        Xn = __double2int_rn(pxn); Yn = __double2int_rn(pyn);
+        X = __double2int_rn(pxn * 32.); Y = __double2int_rn(pyn * 32.);
+    }
     {
-        const int sx = sat_short(__double2int_rn(pxn)), sy = sat_short(__double2int_rn(pyn));
+        const int sx = sat_short(Xn), sy = sat_short(Yn);
         float wv = 0.f;
         if (abl & 8) wv = (float)(sx + sy); else
         if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
@@ -355,8 +370,6 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         }
         o.w = wv;
     }
-    const int X = __double2int_rn(pxn * 32.);
-    const int Y = __double2int_rn(pyn * 32.);
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
     const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
