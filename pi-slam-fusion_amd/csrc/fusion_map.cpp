@@ -590,16 +590,13 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         prof_end();
     } else if (fused) {
         // weightImage (MultiBandMap2DCPU.cpp:396-425): built once per frame size, gathered by the warp
-        static const bool no_wmap = std::getenv("PF_NO_WMAP") != nullptr;      // diagnostics: analytic weight per pixel
-        if (!no_wmap) {
-            if (wmap_rows_ != f.rows || wmap_cols_ != f.cols) {
-                HIP_OK(sync_all());
-                if (!wmap_.reserve((size_t)f.rows * f.cols * 4)) return false;
-                launch_weight32(stream_, (float*)wmap_.p, f.rows, f.cols, opt_.weight_type);
-                wmap_rows_ = f.rows; wmap_cols_ = f.cols;
-            }
-            a.wmap = (const float*)wmap_.p;
+        if (wmap_rows_ != f.rows || wmap_cols_ != f.cols) {
+            HIP_OK(sync_all());
+            if (!wmap_.reserve((size_t)f.rows * f.cols * 4)) return false;
+            launch_weight32(stream_, (float*)wmap_.p, f.rows, f.cols, opt_.weight_type);
+            wmap_rows_ = f.rows; wmap_cols_ = f.cols;
         }
+        a.wmap = (const float*)wmap_.p;
         // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
         struct Win C[kMaxLevels];

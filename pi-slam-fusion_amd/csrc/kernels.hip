@@ -312,6 +312,16 @@ template <bool F32> struct alignas(16) HxT { typename Pix<F32>::WT c[3]; float w
 
 constexpr int LBW = 64, LAW = LBW + 7, LQW = LBW / 2 + 2;      // block width, staged width, half-size width (+halo)
 
+// per-launch scalars kept small on purpose: the warp stage is SGPR-hungry, and whole TileLayout /
+// WarpArgs structs as kernel arguments made the compiler re-load kernel arguments inside the pixel loop
+struct LevelOffsets { uint32_t lap_off, w_off, top_lap_off, top_w_off; };   // byte offsets inside a tile slot
+struct FusedWarp {
+    double M[9];            // destination -> source map
+    long   total;           // bytes in the frame (srows * sstep)
+    const float* wmap;      // srows x scols radial weight plane (the reference's weightImage)
+    int    srows, scols, sstep, cn;
+};
+
 struct LevelArgs {
     int level, rows, cols;        // level i and its canvas extent
     int cx0, cy0, cx1, cy1;       // compute region (block grid origin / extent)
@@ -324,7 +334,7 @@ struct LevelArgs {
 
 // one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
 template <bool F32>
-__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const WarpArgs& a, long total, int x, int y, int abl = 0)
+__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const FusedWarp& a, int x, int y, int abl = 0)
 {
     using T = typename Pix<F32>::T;
     PxT<F32> o;
@@ -359,15 +369,7 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         const int sx = sat_short(Xn), sy = sat_short(Yn);
         float wv = 0.f;
         if (abl & 8) wv = (float)(sx + sy); else
-        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) {
-            if (a.wmap) wv = a.wmap[__mul24(sy, a.scols) + sx]; else {
-            const float dy = (float)sy - a.yc, dx = (float)sx - a.xc;
-            float dis = dy * dy + dx * dx;
-            dis = 1.f - sqrtf(dis) / a.dis_max;
-            wv = a.weight_type == 0 ? dis : dis * dis;
-            if (wv <= 1e-5f) wv = 1e-5f;          // == ((double)wv <= 1e-5): 1e-5f is the largest float below 1e-5
-            }
-        }
+        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) wv = a.wmap[__mul24(sy, a.scols) + sx];
         o.w = wv;
     }
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
@@ -376,8 +378,9 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
     // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes 3..5
     // frames are < 2 GiB and rows/steps fit 24 bits: 32-bit offsets, full-rate 24-bit multiplies
-    const int step32 = (int)a.sstep;
-    const int cn = a.src_cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
+    const long total = a.total;
+    const int step32 = a.sstep;
+    const int cn = a.cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
     const long off0 = (long)(__mul24(sy, step32) + cn * sx);
     const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1) &&
                       off0 + a.sstep + 8 <= total;
@@ -456,7 +459,7 @@ __device__ __forceinline__ WT up_h_val(WT a, WT b, WT c, bool odd, bool le, bool
 
 // max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
 template <bool F32>
-__device__ __forceinline__ void select_store(const TileLayout& lay, int level, const uint64_t* __restrict__ table, int tiles_x,
+__device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, int level, const uint64_t* __restrict__ table, int tiles_x,
                                              int x, int y, const typename Pix<F32>::T v[3], float sw)
 {
     using T = typename Pix<F32>::T;
@@ -465,9 +468,9 @@ __device__ __forceinline__ void select_store(const TileLayout& lay, int level, c
     if (!ent) return;
     const uint64_t slot = ent & ~(uint64_t)1;
     const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
-    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off[level]) + loc;
+    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + w_off) + loc;
     if (!(ent & 1) && !(sw >= *dw)) return;
-    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[level]) + loc * 3;
+    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lap_off) + loc * 3;
     dl[0] = v[0]; dl[1] = v[1]; dl[2] = v[2];
     *dw = sw;
 }
@@ -502,7 +505,7 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
 }
 
 template <bool F32, bool FROM_WARP, int LBH, int LNT, int LS>
-__global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
+__global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, FusedWarp wa, const uint8_t* __restrict__ src,
                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
                                                 const uint64_t* __restrict__ table)
 {
@@ -548,7 +551,6 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
     }
 
     // ---- A
-    const long total = FROM_WARP ? (long)wa.srows * wa.sstep : 0;
     if constexpr (FROM_WARP) {
         // blocks whose halo lies inside the canvas (all but the rim) skip the REFLECT_101 mapping
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, total, x, y, g.ablate);
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y, g.ablate);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         dwv[it] = -1.f;                                   // fresh tile: every weight (>= 0) wins
         if (ent && !(ent & 1)) {
             const int idx = tid + it * LNT, y = y0 + (idx >> 6), x = x0 + (idx & 63);
-            dwv[it] = ((const float PF_GLOBAL*)((ent & ~(uint64_t)1) + lay.w_off[g.level]))[(y & (ts - 1)) * ts + (x & (ts - 1))];
+            dwv[it] = ((const float PF_GLOBAL*)((ent & ~(uint64_t)1) + lay.w_off))[(y & (ts - 1)) * ts + (x & (ts - 1))];
         }
     }
     // ---- H
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
         Bt[p][q] = o;
         if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
             if (g.write_next) gw_out[(long)Y * ncols + X] = o;
-            if (g.top_select) select_store<F32>(lay, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+            if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
         }
     }
     lds_barrier();
@@ -678,9 +680,9 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
 #pragma unroll
             for (int k = 0; k < 3; k++) out[k] = sat_sub(gpx.c[k], cast_up(u0.c[k] + u1.c[k] * 6 + u2.c[k]));
         }
-        T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[g.level]) + loc * 3;
+        T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off) + loc * 3;
         dl[0] = out[0]; dl[1] = out[1]; dl[2] = out[2];
-        ((float PF_GLOBAL*)(slot + lay.w_off[g.level]))[loc] = gpx.w;
+        ((float PF_GLOBAL*)(slot + lay.w_off))[loc] = gpx.w;
     }
     if (st + 1 < LS) {
         lds_barrier();                                           // every read of A / U of this step is done
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(LNT) void k_level(TileLayout lay, LevelArgs g, Warp
 //      thread, prefetched after A
 // LDS: A + B only (54 KB fp32 / 40.6 KB int16).
 template <bool F32, bool FROM_WARP, int LBH, int LNT>
-__global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, WarpArgs wa, const uint8_t* __restrict__ src,
+__global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g, FusedWarp wa, const uint8_t* __restrict__ src,
                                                  const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
                                                  const uint64_t* __restrict__ table)
 {
@@ -734,7 +736,6 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
     uint64_t ent = (dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
 
     // ---- A
-    const long total = FROM_WARP ? (long)wa.srows * wa.sstep : 0;
     if constexpr (FROM_WARP) {
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
         int r = tid / LAW, c = tid - r * LAW;
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, total, x, y, g.ablate);
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y, g.ablate);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
     const uint64_t slot = ent & ~(uint64_t)1;
     const int loc0 = (dy0 & (ts - 1)) * ts + (dx0 & (ts - 1));
     if (ent && !(ent & 1)) {
-        const float PF_GLOBAL* wp = (const float PF_GLOBAL*)(slot + lay.w_off[g.level]) + loc0;
+        const float PF_GLOBAL* wp = (const float PF_GLOBAL*)(slot + lay.w_off) + loc0;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -814,7 +815,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
             Bt[p][q] = o;
             if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
                 if (g.write_next) gw_out[(long)Y * ncols + X] = o;
-                if (g.top_select) select_store<F32>(lay, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+                if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
             }
         }
     }
@@ -853,8 +854,8 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(TileLayout lay, LevelArgs g, 
             }
         }
     }
-    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off[g.level]) + loc0 * 3;
-    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off[g.level]) + loc0;
+    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off) + loc0 * 3;
+    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off) + loc0;
     T o00[3], o01[3], o10[3], o11[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -891,9 +892,14 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     g.ablate = ablate;
     if (g.nbx <= 0 || g.nby <= 0) return;
     dim3 grid(g.nbx * g.nby);
-    WarpArgs w{};
-    if (wa) w = *wa;
-#define PF_LAUNCH(K, F, W, ...) hipLaunchKernelGGL((K<F, W, __VA_ARGS__>), grid, dim3(512), 0, s, lay, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
+    FusedWarp w{};
+    if (wa) {
+        for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
+        w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
+        w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
+    }
+    LevelOffsets lo{ lay.lap_off[level], lay.w_off[level], lay.lap_off[level + 1], lay.w_off[level + 1] };
+#define PF_LAUNCH(K, F, W, ...) hipLaunchKernelGGL((K<F, W, __VA_ARGS__>), grid, dim3(512), 0, s, lo, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
     if (use4) {
         if (lay.f32) { if (wa) PF_LAUNCH(k_level, true, true, 16, 512, 1); else PF_LAUNCH(k_level, true, false, 16, 512, 1); }
         else         { if (wa) PF_LAUNCH(k_level, false, true, 16, 512, 1); else PF_LAUNCH(k_level, false, false, 16, 512, 1); }
