@@ -191,11 +191,16 @@ class Map2D:
         p, pp = _pose(pose)
         if img is None:
             return bool(lib().pf_feed(self._h, None, pp))
-        img = np.ascontiguousarray(img)
+        img = np.asarray(img)
+        step = 0
+        if img.ndim == 3 and img.dtype == np.uint8 and img.strides[2] == 1 and img.strides[1] == img.shape[2] and img.strides[0] >= img.shape[1] * img.shape[2]:
+            step = img.strides[0]                       # row-padded view (cv::Mat::step): handed over as is
+        else:
+            img = np.ascontiguousarray(img)
         typ = -1
         if img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] in (3, 4):
             typ = PF_8UC3 if img.shape[2] == 3 else PF_8UC4      # BGRA as the tracker holds it (TrackerOpt.cpp:376)
-        im = Image(img.shape[0], img.shape[1], typ, img.ctypes.data, 0)
+        im = Image(img.shape[0], img.shape[1], typ, img.ctypes.data, step)
         return bool(lib().pf_feed(self._h, C.byref(im), pp))
 
     def feed_device(self, data_ptr, rows, cols, pose, step=0):

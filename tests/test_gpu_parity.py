@@ -220,3 +220,19 @@ def test_stress_geometry_8000x6000_7band(pf, orc, force_float):
     g, o = run_pair(pf, orc, cam, poses[:1], [frame], force_float=force_float, band_number=7)
     assert g.num_levels == 8 and len(o.tiles()) >= 800
     assert compare_maps(g, o) == []
+
+
+def test_row_padded_frames(pf):
+    """cv::Mat::step > cols*channels (a ROI of a wider buffer) is honoured by the H2D copy."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(3, seed=4)
+    a = pf.Map2D.create(pf.TypeMultiBandCPU, False); b = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        wide = wl.noise_frame(480, 700, 70 + k)
+        view = wide[:, 30:670]                         # 640 columns, row step 2100 bytes
+        assert view.strides[0] == 2100 and not view.flags["C_CONTIGUOUS"]
+        assert a.feed(view, p) and b.feed(np.ascontiguousarray(view), p)
+    a.sync(); b.sync()
+    assert map_digest(a) == map_digest(b)
