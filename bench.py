@@ -61,6 +61,35 @@ def cpu_baseline(wl, cam, poses, prep, frames_host, force_float, budget_s=15.0, 
             "sample": "first %d frames of the same 4000x3000 workload, 1 thread, %.1f s" % (n, dt)}
 
 
+def cpu_baseline_allcores(force_float, budget_s=10.0):
+    """BASELINE.md B2 ("generous"): the same oracle with its row / tile loops under OpenMP, all host
+    cores, in a child process (the library flavour is chosen per process; the child never touches the GPU)."""
+    import subprocess
+    code = (
+        "import sys, time, json, os; sys.path.insert(0, %r)\n"
+        "nth = min(16, len(os.sched_getaffinity(0)))        # a 1-GPU box gives this job a 16-CPU share\n"
+        "os.environ['OMP_NUM_THREADS'] = str(nth)\n"
+        "import bench, importlib\n"
+        "from oracle import orc\n"
+        "orc.use_openmp()\n"
+        "pf = bench.load_package(); wl = importlib.import_module('pi_slam_fusion_amd.workloads')\n"
+        "cam, poses = wl.cfg2(64)\n"
+        "o = orc.OracleMap(force_float=%d); assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:20])\n"
+        "fr = [wl.noise_frame(3000, 4000, k) for k in range(2)]\n"
+        "n, t0 = 0, time.perf_counter()\n"
+        "while n < 64 and time.perf_counter() - t0 < %f:\n"
+        "    o.feed(fr[n %% 2], poses[n]); n += 1\n"
+        "dt = time.perf_counter() - t0\n"
+        "print(json.dumps({'value': round(n / dt, 4), 'unit': 'keyframes/s', 'cores': nth, 'kind': 'port',\n"
+        "                  'sample': 'first %%d frames, OpenMP over rows/tiles, %%.1f s' %% (n, dt)}))\n"
+    ) % (ROOT, force_float, budget_s)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +254,9 @@ def main():
         if not args.no_cpu:
             hostf = [f.cpu().numpy() for f in frames[:2]]
             out["cpu_baseline"] = cpu_baseline(wl, cam, sorties[0], prep, hostf, force_float)
+            allc = cpu_baseline_allcores(force_float)
+            if allc:
+                out["cpu_baseline_allcores"] = allc
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

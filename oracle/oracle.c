@@ -10,6 +10,9 @@
 #include <string.h>
 #include <math.h>
 #include <limits.h>
+#ifdef ORC_OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------ helpers */
 
@@ -169,6 +172,9 @@ void orc_warp_nearest_const_32f(const float* src, int srows, int scols, int cn,
     if (!orc_invert3x3(M0, M)) memset(M, 0, sizeof(M));
     int bh0 = drows < 16 ? drows : 16;
     int bw0 = (1024 / bh0) < dcols ? (1024 / bh0) : dcols;
+#ifdef ORC_OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int y = 0; y < drows; y++) {
         float* D = dst + (size_t)y * dcols * cn;
         for (int xb = 0; xb < dcols; xb += bw0) {
@@ -624,7 +630,10 @@ static int render_frame(orc_map* m, const uint8_t* bgr, int rows, int cols, cons
     for (int i = 0; i < L; i++)
         orc_pyr_down_32f(wp[i], crow >> i, ccol >> i, 1, wp[i + 1]);
 
-    /* Apply, .cpp:476-555 */
+    /* Apply, .cpp:476-555 (tiles are independent) */
+#ifdef ORC_OPENMP
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+#endif
     for (int x = xminInt; x < xmaxInt; x++)
         for (int y = yminInt; y < ymaxInt; y++) {
             orc_tile* ele = m->data[y * m->w + x];

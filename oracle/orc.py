@@ -24,11 +24,23 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
 
 
+def use_openmp():
+    """Switch this process to liboracle_omp.so (same code, row/tile loops in parallel): the "generous"
+    all-core CPU baseline of BASELINE.md (B2).  Call before the first lib()."""
+    global _LIB, _NAME
+    assert _LIB is None, "oracle library already loaded"
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_omp.so"])
+    _NAME = "liboracle_omp.so"
+
+
+_NAME = "liboracle.so"
+
+
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.path.join(_HERE, _NAME)
     if not os.path.exists(path):
         build()
     L = C.CDLL(path)

@@ -86,3 +86,20 @@ def test_perspective_transform_same_in_product_and_oracle(pf, orc):
         for i in range(4):      # it is a homography through the four correspondences
             v = Mp @ np.array([src[2 * i], src[2 * i + 1], 1.0])
             assert np.allclose(v[:2] / v[2], dst[2 * i:2 * i + 2], atol=1e-6)
+
+
+def test_weight_map_helpers(pf):
+    """MultiBandMap2DCPUEle::normalizeUsingWeightMap / mulWeightMap (MultiBandMap2DCPU.cpp:57-75):
+    no caller in the reference; host loops kept for API completeness (row a17)."""
+    rng = np.random.RandomState(1)
+    w = rng.uniform(0, 1, 1000).astype(np.float32)
+    src = rng.uniform(0, 1, (1000, 3)).astype(np.float32)
+    a = src.copy()
+    assert pf.lib().pf_mul_weight_map(w.ctypes.data, a.ctypes.data, 1000) == 1
+    assert np.array_equal(a, src * w[:, None])
+    b = src.copy()
+    assert pf.lib().pf_normalize_using_weight_map(w.ctypes.data, b.ctypes.data, 1000) == 1
+    d = (w.astype(np.float64) + 1e-5).astype(np.float32)                 # *weightP + 1e-5 narrowed to the float divisor
+    inv = (1.0 / d.astype(np.float64)).astype(np.float32)                 # Point3_ operator/ multiplies by (1./b)
+    assert np.array_equal(b, inv[:, None] * src)
+    assert pf.lib().pf_mul_weight_map(None, a.ctypes.data, 10) == 0
