@@ -84,3 +84,24 @@ def test_halo_blend_and_gathered_save(pf, force_float):
         assert shards[0].tile_import(t[0], t[1], buf.data_ptr())
     (a, ao), (b, bo) = shards[0].save_to_memory(), ref.save_to_memory()
     assert ao == bo and np.array_equal(a, b)
+
+
+def test_eight_shards_on_one_gpu(pf):
+    """The 8-GPU layout rehearsed on one card: eight shard maps (one per rank of a node), every one fed
+    every keyframe; their tiles partition the unsharded mosaic exactly."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    base = jitter_poses(12, seed=29, step=(0.0, 0.0))
+    poses = [[(k % 4) * 60.0 + p[0], (k // 4) * 50.0 + p[1]] + p[2:] for k, p in enumerate(base)]
+    frames = [wl.noise_frame(480, 640, 800 + k) for k in range(len(poses))]
+    (ref,) = build(pf, cam, poses, frames, 1, 1, 0, scale=2.0)
+    shards = build(pf, cam, poses, frames, 8, 1, 0, scale=2.0)
+    dref = map_digest(ref)
+    got, owners = {}, set()
+    for r, m in enumerate(shards):
+        d = map_digest(m)
+        assert not (set(d) & set(got))
+        got.update(d)
+        if d:
+            owners.add(r)
+    assert got == dref and len(owners) >= 6
