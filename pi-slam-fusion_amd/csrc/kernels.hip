@@ -572,7 +572,9 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
 #pragma unroll
     for (int it = 0; it < ND; it++) {
         uint64_t ent = ents[it];
-        if (ts >= LBW)        // a 64-pixel row segment lies in one tile: make the slot address wave-uniform
+        // when this block's 64-pixel row segments lie inside one tile (always on an unsharded canvas; a shard's
+        // halo-extended region may start 8 px left of a tile edge) make the slot address wave-uniform
+        if ((x0 >> sh) == ((x0 + LBW - 1) >> sh))
             ent = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ent >> 32)) << 32) |
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ent);
         ents[it] = ent;

@@ -105,3 +105,20 @@ def test_eight_shards_on_one_gpu(pf):
         if d:
             owners.add(r)
     assert got == dref and len(owners) >= 6
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_shard_regions_not_tile_aligned(pf, force_float):
+    """A shard whose owned tiles start in the middle of the canvas gets compute regions that begin a few
+    pixels left of / above a tile edge (the pyramid halo): 3 shards over wide canvases, every frame."""
+    wl = workloads()
+    cam = [1280, 480, 700, 700, 640, 240]
+    poses = jitter_poses(6, seed=37, step=(35.0, 9.0), yaw_deg=8, height=140.0)
+    frames = [wl.noise_frame(480, 1280, 300 + k) for k in range(len(poses))]
+    (ref,) = build(pf, cam, poses, frames, 1, 1, force_float, scale=2.0)
+    shards = build(pf, cam, poses, frames, 3, 1, force_float, scale=2.0)
+    assert max(t[0] for t in ref.tiles()) - min(t[0] for t in ref.tiles()) >= 6      # canvases many tiles wide
+    got = {}
+    for m in shards:
+        got.update(map_digest(m))
+    assert got == map_digest(ref)
