@@ -52,8 +52,9 @@ typedef struct pf_options {
     int    shard_count;      /* ... of shard_count (1 = own every tile)      */
     int    shard_block;      /* spatial-hash cell edge in tiles (default 8)  */
     int    max_queue;        /* feed queue cap, drop-oldest (20)    .cpp:302 */
-    int    fused;            /* 1 (default): fused per-level kernels; 0: one kernel per
-                                reference op (warp / pyrDown / Laplacian+select)     */
+    int    fused;            /* 1 (default): fused per-level kernels; 2: the same in the
+                                4-stage 64x16-block shape; 0: one kernel per reference
+                                op (warp / pyrDown / Laplacian+select)               */
 } pf_options;
 
 typedef struct pf_map pf_map;

@@ -638,7 +638,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             if (i == 0) bytes += (double)a.src_cn * f.rows * f.cols;
             prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
             launch_level(st, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
-                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab);
+                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab, opt_.fused);
             prof_end();
             HIP_OK(hipEventRecord(lvl_ev_[i][slot], st));
         }

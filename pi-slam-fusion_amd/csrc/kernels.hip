@@ -715,8 +715,12 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     using Px = PxT<F32>;
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
     static_assert(LNT == 32 * (LBH / 2), "one thread per 2x2 output quad");
+    struct Bx { T c[F32 ? 3 : 4]; };                            // stage D needs G_{i+1} only, not W_{i+1}
     __shared__ Px A[LAH][LAW];
-    __shared__ Px Bt[LQH][LQW];
+    __shared__ Bx Bt[LQH][LQW];
+    // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
+    // workgroups per CU, int16 under 32 for four
+    static_assert(sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget");
 
     const int nblk = g.nbx * g.nby;
     int b = blockIdx.x;
@@ -775,19 +779,12 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
         const int pp = idx / LQW, q = idx - pp * LQW;
         const int X = bx0 + q;
         if (X < 0 || X >= ncols) continue;
+        // rows are consumed as they arrive (output e needs rows 2e .. 2e+4) and a compiler memory fence after each
+        // row keeps the 35 LDS reads from being hoisted together: at most 5 row sums + one row of taps are live
         WT h[7][3]; float hw[7];
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const Px* row = &A[4 * pp + j][2 * q];
-            const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
-#pragma unroll
-            for (int k = 0; k < 3; k++) h[j][k] = (WT)a2.c[k] * 6 + ((WT)a1.c[k] + (WT)a3.c[k]) * 4 + (WT)a0.c[k] + (WT)a4.c[k];
-            hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
+        auto emit = [&](int e) {
             const int p = 2 * pp + e, Y = by0 + p;
-            if (Y < 0 || Y >= nrows) continue;
+            if (Y < 0 || Y >= nrows) return;
             Px o;
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -814,11 +811,27 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
                     o.w = (r2 * 6 + (r1 + r3) * 4 + r0 + r4) * (1.f / 256);
             }
             if constexpr (!F32) o.pad = 0;
-            Bt[p][q] = o;
+            {
+                Bx ob; ob.c[0] = o.c[0]; ob.c[1] = o.c[1]; ob.c[2] = o.c[2];
+                if constexpr (!F32) ob.c[3] = 0;
+                Bt[p][q] = ob;
+            }
             if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
                 if (g.write_next) gw_out[(long)Y * ncols + X] = o;
                 if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
             }
+        };
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const Px* row = &A[4 * pp + j][2 * q];
+            const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) h[j][k] = (WT)a2.c[k] * 6 + ((WT)a1.c[k] + (WT)a3.c[k]) * 4 + (WT)a0.c[k] + (WT)a4.c[k];
+            hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
+            // pin the sums here: otherwise they are sunk into emit()'s range check and the raw taps stay live
+            asm volatile("" : "+v"(h[j][0]), "+v"(h[j][1]), "+v"(h[j][2]), "+v"(hw[j]) :: "memory");
+            if (j == 4) emit(0);
+            if (j == 6) emit(1);
         }
     }
     lds_barrier();
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     WT he[3][3], ho[3][3];                                   // [row][channel]: even / odd output column
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        const Px a = Bt[rows3[r]][ja], bq = Bt[rows3[r]][j], c = Bt[rows3[r]][jc];
+        const Bx a = Bt[rows3[r]][ja], bq = Bt[rows3[r]][j], c = Bt[rows3[r]][jc];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             if (F32 && edge) {
@@ -876,18 +889,18 @@ size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<fa
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
                   int tiles_x, bool top_select, bool write_next, const WarpArgs* wa, const uint8_t* src,
-                  const void* gw_in, void* gw_out, const uint64_t* table)
+                  const void* gw_in, void* gw_out, const uint64_t* table, int shape)
 {
     LevelArgs g{};
     g.level = level; g.rows = rows; g.cols = cols; g.cx0 = cx0; g.cy0 = cy0; g.cx1 = cx1; g.cy1 = cy1;
     g.tiles_x = tiles_x; g.top_select = top_select; g.write_next = write_next;
-    // Two code shapes of the same computation: k_level (4 barriers, H tile in LDS, ~50 VGPRs) and
-    // k_level3 (2 barriers, no H tile, 2x2 output quads; 96 VGPRs int16, 128 + spills fp32).
-    // Measured on MI355X (cfg-A): fp32 is fastest with k_level on 64x16 blocks (3 workgroups per
-    // CU), int16 with k_level3 on 64x32 blocks.  PF_KLEVEL=4|3 forces one shape (diagnostics).
+    // Two code shapes of the same computation: k_level (4 barriers, H tile in LDS, 64x16 blocks) and
+    // k_level3 (2 barriers, no H tile, 2x2 output quads, 64x32 blocks; 73 VGPRs / 51.6 KB LDS fp32 ->
+    // 3 workgroups per CU, 56 VGPRs / 38.1 KB int16 -> 4).  Measured on MI355X (cfg-A) k_level3 is
+    // the faster one for both pyramid types; shape 2 (pf_options.fused = 2) or PF_KLEVEL=4 selects k_level.
     static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
-    const bool use4 = force == 4 || (force != 3 && lay.f32);
+    const bool use4 = force == 4 || (force != 3 && shape == 2);
     const int BH = use4 ? 16 : 32;
     const int LSTEPS = 1;     // rolling strips (k_level<..., LS>1>) measured slower on MI355X: kept at one block per workgroup
     g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + BH * LSTEPS - 1) / (BH * LSTEPS);

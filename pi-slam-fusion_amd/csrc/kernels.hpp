@@ -72,7 +72,7 @@ void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const vo
 size_t level_px_bytes(bool f32);
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
                   int tiles_x, bool top_select, bool write_next, const WarpArgs* wa, const uint8_t* src,
-                  const void* gw_in, void* gw_out, const uint64_t* table);
+                  const void* gw_in, void* gw_out, const uint64_t* table, int shape = 1);   // shape 2: 4-stage k_level
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
 void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,
