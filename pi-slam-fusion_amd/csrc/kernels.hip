@@ -332,11 +332,22 @@ struct LevelArgs {
     int ablate;                   // diagnostics only (PF_ABLATE): bit0 skip A math, bit1 skip H/B, bit2 skip U/D
 };
 
+// 1/d exactly as the compiler's IEEE fp64 division computes it when no operand scaling is needed
+// (v_div_scale_f64 and v_div_fixup_f64 are identities for 2^-500 < |d| < 2^500, v_div_fmas_f64 is a plain
+// fma): v_rcp_f64, two Newton steps, quotient q = 1*r, one remainder correction -> correctly rounded.
+__device__ __forceinline__ double rcp_mid_range(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
+}
+
 // one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
 template <bool F32>
-__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const FusedWarp& a, int x, int y, int abl = 0)
+__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const FusedWarp& a, int x, int y)
 {
-    using T = typename Pix<F32>::T;
     PxT<F32> o;
     const int xb = x & ~63, x1 = x & 63;                     // OpenCV's 64-wide coordinate block
     const double X0 = a.M[0] * xb + a.M[1] * y + a.M[2];
@@ -344,54 +355,55 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
     const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
     const double W  = W0 + a.M[6] * x1;
     const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
-    double Wn = W ? 1. / W : 0;
-    if (abl & 32) Wn = (double)(1.f / (float)W);
     // nearest coordinate p = (X0+M0*x1)*(1/W); the 1/32-px coordinate (X0+M0*x1)*(32/W) equals 32*p
     // bit for bit (32/W == 32*(1/W) and scaling by a power of two commutes with rounding).
+    // Common case, decided per wave: W in the mid range (reciprocal without the scale/fixup steps) and both
+    // coordinates far inside the int range, where round-half-even comes from one fp64 add of 1.5*2^52 whose
+    // low dword IS the integer.  Anything else (W == 0, degenerate homographies) takes the general forms;
     // v_cvt_i32_f64 saturates, which is exactly clamp-to-int-range followed by cvRound.
-    const double pxn = xn * Wn, pyn = yn * Wn;
-    // cvRound of the four coordinates.  When the whole wave is far inside the int range (always, short of a
-    // degenerate homography) round-half-even comes from one fp64 add of 1.5*2^52 whose low dword IS the
-    // integer -- instead of v_rndne_f64 + v_cvt_i32_f64 per coordinate.
     int Xn, Yn, X, Y;
-    const bool tame = fabs(pxn) < 3.0e7 && fabs(pyn) < 3.0e7;
-    if (__builtin_amdgcn_ballot_w64(!tame) == 0) {
-        constexpr double kMagic = 6755399441055744.0;
-        Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
-        Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
-        X  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn * 32. + kMagic);
-        Y  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn * 32. + kMagic);
-    } else {
-        Xn = __double2int_rn(pxn); Yn = __double2int_rn(pyn);
-        X = __double2int_rn(pxn * 32.); Y = __double2int_rn(pyn * 32.);
+    {
+        const double Wn = rcp_mid_range(W);
+        const double pxn = xn * Wn, pyn = yn * Wn;
+        const bool tame = fabs(W) > 0x1p-500 && fabs(W) < 0x1p500 && fabs(pxn) < 3.0e7 && fabs(pyn) < 3.0e7;
+        if (__builtin_amdgcn_ballot_w64(!tame) == 0) {
+            constexpr double kMagic = 6755399441055744.0;
+            Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
+            Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
+            X  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn * 32. + kMagic);
+            Y  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn * 32. + kMagic);
+        } else {
+            const double Wd = W ? 1. / W : 0;
+            const double qx = xn * Wd, qy = yn * Wd;
+            Xn = __double2int_rn(qx); Yn = __double2int_rn(qy);
+            X = __double2int_rn(qx * 32.); Y = __double2int_rn(qy * 32.);
+        }
     }
     {
         const int sx = sat_short(Xn), sy = sat_short(Yn);
         float wv = 0.f;
-        if (abl & 8) wv = (float)(sx + sy); else
-        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) wv = a.wmap[__mul24(sy, a.scols) + sx];
+        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) wv = *(const float*)((const char*)a.wmap + ((uint32_t)(__mul24(sy, a.scols) + sx) << 2));
         o.w = wv;
     }
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
     const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
     float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
-    // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes 3..5
-    // frames are < 2 GiB and rows/steps fit 24 bits: 32-bit offsets, full-rate 24-bit multiplies
-    const long total = a.total;
-    const int step32 = a.sstep;
+    // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes cn..cn+2
+    // (v_perm_b32 with a per-launch selector).  Frames are < 2 GiB and rows/steps fit 24 bits: 32-bit
+    // unsigned offsets from the frame base, full-rate 24-bit multiplies.
     const int cn = a.cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
-    const long off0 = (long)(__mul24(sy, step32) + cn * sx);
-    const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1) &&
-                      off0 + a.sstep + 8 <= total;
+    const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;
+    const uint32_t total = (uint32_t)a.total, step = (uint32_t)a.sstep;
+    // strictly inside the frame and not on its last two rows: both 8-byte reads stay inside the buffer
+    const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 2);
     if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
-        // whole wave strictly inside the frame: no border mapping, taps are (lo, hi) of each row
+        const uint32_t off0 = (uint32_t)(__mul24(sy, a.sstep) + __mul24(cn, sx));
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            uint64_t bits;
-            if (abl & 16) bits = (uint64_t)off0 * 0x9E3779B97F4A7C15ull; else
-            __builtin_memcpy(&bits, src + off0 + (j ? a.sstep : 0), 8);
-            const uint32_t lo = (uint32_t)bits, hi = cn == 3 ? (uint32_t)(bits >> 24) : (uint32_t)(bits >> 32);
+            typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+            const u2 bits = *(const u2*)(src + (j ? off0 + step : off0));
+            const uint32_t lo = bits.x, hi = __builtin_amdgcn_perm(bits.y, bits.x, hisel);
             v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
             v[2 * j + 1][0] = (float)(hi & 0xff); v[2 * j + 1][1] = (float)((hi >> 8) & 0xff); v[2 * j + 1][2] = (float)((hi >> 16) & 0xff);
         }
@@ -406,15 +418,15 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         const bool t0hi = sx0 != xbase, t1hi = sx1 != xbase;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const long off = (long)(__mul24(j ? sy1 : sy0, step32) + cn * xbase);
+            const uint32_t off = (uint32_t)(__mul24(j ? sy1 : sy0, a.sstep) + __mul24(cn, xbase));
             uint64_t bits;
             if (off + 8 > total) {           // last bytes of the frame: never read past it
-                const int back = (int)(off + 8 - total);
+                const uint32_t back = off + 8 - total;
                 __builtin_memcpy(&bits, src + (off - back), 8);
                 bits >>= 8 * back;
             } else
                 __builtin_memcpy(&bits, src + off, 8);
-            const uint32_t lo = (uint32_t)bits, hi = cn == 3 ? (uint32_t)(bits >> 24) : (uint32_t)(bits >> 32);
+            const uint32_t lo = (uint32_t)bits, hi = __builtin_amdgcn_perm((uint32_t)(bits >> 32), (uint32_t)bits, hisel);
             const float l0 = (float)(lo & 0xff), l1 = (float)((lo >> 8) & 0xff), l2 = (float)((lo >> 16) & 0xff);
             const float h0 = (float)(hi & 0xff), h1 = (float)((hi >> 8) & 0xff), h2 = (float)((hi >> 16) & 0xff);
             v[2 * j][0] = t0hi ? h0 : l0; v[2 * j][1] = t0hi ? h1 : l1; v[2 * j][2] = t0hi ? h2 : l2;
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y, g.ablate);
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y, g.ablate);
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }

@@ -3,6 +3,7 @@
 
   kernel stats : tools/pmc_summary.py stats <dir with *_kernel_stats.csv> > profiles/<name>.md
   HBM traffic  : tools/pmc_summary.py traffic <fetch dir> <write dir> <dtype> [profiles/pmc_traffic.json]
+  SQ counters  : tools/pmc_summary.py counters <pmc dir> ...
 
 Traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
 separate --pmc passes; both are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
@@ -75,8 +76,25 @@ def traffic(fd, wd, dtype, out):
     print(json.dumps(res))
 
 
+def counters(dirs):
+    """mean per launch of every counter found in the given --pmc output dirs, per kernel"""
+    acc = defaultdict(lambda: defaultdict(list))
+    for d in dirs:
+        for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+            s = short(r["Kernel_Name"])
+            if s:
+                acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k in sorted(acc):
+        print("## %s" % k)
+        for c in sorted(acc[k]):
+            v = acc[k][c]
+            print("| %s | %d launches | %.4g per launch |" % (c, len(v), sum(v) / len(v)))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2:])
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
