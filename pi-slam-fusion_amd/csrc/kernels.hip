@@ -305,6 +305,8 @@ void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const vo
 // Out-of-canvas halo entries hold the BORDER_REFLECT_101 pixel, so H/B need
 // no border logic; pyrUp's asymmetric edge rules are applied on global
 // coordinates.  All arithmetic orders are those of the unfused kernels.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 template <bool F32> struct PxT;
 template <> struct alignas(16) PxT<true>  { float c[3]; float w; };
 template <> struct alignas(4)  PxT<false> { short c[3]; short pad; float w; };
@@ -791,59 +793,102 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
         const int pp = idx / LQW, q = idx - pp * LQW;
         const int X = bx0 + q;
         if (X < 0 || X >= ncols) continue;
-        // rows are consumed as they arrive (output e needs rows 2e .. 2e+4) and a compiler memory fence after each
-        // row keeps the 35 LDS reads from being hoisted together: at most 5 row sums + one row of taps are live
-        WT h[7][3]; float hw[7];
-        auto emit = [&](int e) {
-            const int p = 2 * pp + e, Y = by0 + p;
-            if (Y < 0 || Y >= nrows) return;
-            Px o;
+        // rows are consumed as they arrive (output e needs rows 2e .. 2e+4); each row's sums are pinned where they
+        // are formed, otherwise the compiler sinks them into emit()'s range check and keeps the 35 raw taps live
+        if constexpr (F32) {
+            // packed fp32: a Px is two float2 halves (c0,c1) (c2,w); all four components take the same forms
+            f2 hl[7], hh[7];
+            const bool vec_all = X * 3 + 2 < vec_img && X < vec_w;          // every component in PyrDownVec_32f's range
+            const bool uni = __builtin_amdgcn_ballot_w64(!vec_all) == 0;
+            auto emit = [&](int e) {
+                const int p = 2 * pp + e, Y = by0 + p;
+                if (Y < 0 || Y >= nrows) return;
+                Px o;
+                if (uni) {
+                    auto vsum = [](f2 r0, f2 r1, f2 r2, f2 r3, f2 r4) {
+                        f2 a = r0 + r4;
+                        const f2 bb = (r1 + r3) + r2;
+                        a = a + (r2 + r2);
+                        return (a + bb * 4.f) * (1.f / 256);
+                    };
+                    const f2 ol = vsum(hl[2 * e], hl[2 * e + 1], hl[2 * e + 2], hl[2 * e + 3], hl[2 * e + 4]);
+                    const f2 oh = vsum(hh[2 * e], hh[2 * e + 1], hh[2 * e + 2], hh[2 * e + 3], hh[2 * e + 4]);
+                    o.c[0] = ol.x; o.c[1] = ol.y; o.c[2] = oh.x; o.w = oh.y;
+                } else {
+                    float out[4];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const WT r0 = h[2 * e][k], r1 = h[2 * e + 1][k], r2 = h[2 * e + 2][k], r3 = h[2 * e + 3][k], r4 = h[2 * e + 4][k];
-                if constexpr (F32) {
-                    if (X * 3 + k < vec_img) {
+                    for (int k = 0; k < 4; k++) {
+                        auto at = [&](int j) { return k < 2 ? hl[j][k] : hh[j][k - 2]; };
+                        const float r0 = at(2 * e), r1 = at(2 * e + 1), r2 = at(2 * e + 2), r3 = at(2 * e + 3), r4 = at(2 * e + 4);
+                        if (k < 3 ? X * 3 + k < vec_img : X < vec_w) {
+                            float a = r0 + r4;
+                            const float bb = (r1 + r3) + r2;
+                            a = a + (r2 + r2);
+                            out[k] = (a + bb * 4.f) * (1.f / 256);
+                        } else
+                            out[k] = (r2 * 6 + (r1 + r3) * 4 + r0 + r4) * (1.f / 256);
+                    }
+                    o.c[0] = out[0]; o.c[1] = out[1]; o.c[2] = out[2]; o.w = out[3];
+                }
+                {
+                    Bx ob; ob.c[0] = o.c[0]; ob.c[1] = o.c[1]; ob.c[2] = o.c[2];
+                    Bt[p][q] = ob;
+                }
+                if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
+                    if (g.write_next) gw_out[(long)Y * ncols + X] = o;
+                    if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const f4* row = (const f4*)&A[4 * pp + j][2 * q];
+                const f4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+                hl[j] = a2.xy * 6.f + (a1.xy + a3.xy) * 4.f + a0.xy + a4.xy;
+                hh[j] = a2.zw * 6.f + (a1.zw + a3.zw) * 4.f + a0.zw + a4.zw;
+                asm volatile("" : "+v"(hl[j]), "+v"(hh[j]) :: "memory");
+                if (j == 4) emit(0);
+                if (j == 6) emit(1);
+            }
+        } else {
+            int h[7][3]; float hw[7];
+            auto emit = [&](int e) {
+                const int p = 2 * pp + e, Y = by0 + p;
+                if (Y < 0 || Y >= nrows) return;
+                Px o;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    o.c[k] = cast_down(h[2 * e + 2][k] * 6 + (h[2 * e + 1][k] + h[2 * e + 3][k]) * 4 + h[2 * e][k] + h[2 * e + 4][k]);
+                {
+                    const float r0 = hw[2 * e], r1 = hw[2 * e + 1], r2 = hw[2 * e + 2], r3 = hw[2 * e + 3], r4 = hw[2 * e + 4];
+                    if (X < vec_w) {
                         float a = r0 + r4;
                         const float bb = (r1 + r3) + r2;
                         a = a + (r2 + r2);
-                        o.c[k] = (a + bb * 4.f) * (1.f / 256);
+                        o.w = (a + bb * 4.f) * (1.f / 256);
                     } else
-                        o.c[k] = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
-                } else
-                    o.c[k] = cast_down(r2 * 6 + (r1 + r3) * 4 + r0 + r4);
-            }
-            {
-                const float r0 = hw[2 * e], r1 = hw[2 * e + 1], r2 = hw[2 * e + 2], r3 = hw[2 * e + 3], r4 = hw[2 * e + 4];
-                if (X < vec_w) {
-                    float a = r0 + r4;
-                    const float bb = (r1 + r3) + r2;
-                    a = a + (r2 + r2);
-                    o.w = (a + bb * 4.f) * (1.f / 256);
-                } else
-                    o.w = (r2 * 6 + (r1 + r3) * 4 + r0 + r4) * (1.f / 256);
-            }
-            if constexpr (!F32) o.pad = 0;
-            {
-                Bx ob; ob.c[0] = o.c[0]; ob.c[1] = o.c[1]; ob.c[2] = o.c[2];
-                if constexpr (!F32) ob.c[3] = 0;
-                Bt[p][q] = ob;
-            }
-            if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
-                if (g.write_next) gw_out[(long)Y * ncols + X] = o;
-                if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
-            }
-        };
+                        o.w = (r2 * 6 + (r1 + r3) * 4 + r0 + r4) * (1.f / 256);
+                }
+                o.pad = 0;
+                {
+                    Bx ob; ob.c[0] = o.c[0]; ob.c[1] = o.c[1]; ob.c[2] = o.c[2]; ob.c[3] = 0;
+                    Bt[p][q] = ob;
+                }
+                if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
+                    if (g.write_next) gw_out[(long)Y * ncols + X] = o;
+                    if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
+                }
+            };
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const Px* row = &A[4 * pp + j][2 * q];
-            const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+            for (int j = 0; j < 7; j++) {
+                const Px* row = &A[4 * pp + j][2 * q];
+                const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
 #pragma unroll
-            for (int k = 0; k < 3; k++) h[j][k] = (WT)a2.c[k] * 6 + ((WT)a1.c[k] + (WT)a3.c[k]) * 4 + (WT)a0.c[k] + (WT)a4.c[k];
-            hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
-            // pin the sums here: otherwise they are sunk into emit()'s range check and the raw taps stay live
-            asm volatile("" : "+v"(h[j][0]), "+v"(h[j][1]), "+v"(h[j][2]), "+v"(hw[j]) :: "memory");
-            if (j == 4) emit(0);
-            if (j == 6) emit(1);
+                for (int k = 0; k < 3; k++) h[j][k] = (int)a2.c[k] * 6 + ((int)a1.c[k] + (int)a3.c[k]) * 4 + (int)a0.c[k] + (int)a4.c[k];
+                hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
+                asm volatile("" : "+v"(h[j][0]), "+v"(h[j][1]), "+v"(h[j][2]), "+v"(hw[j]) :: "memory");
+                if (j == 4) emit(0);
+                if (j == 6) emit(1);
+            }
         }
     }
     lds_barrier();
@@ -866,6 +911,36 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     // int16: edge forms are the interior form on reflected (left) / replicated (right) neighbours
     const int ja = (le && !F32) ? (one ? j : j + 1) : j - 1, jc = (re && !F32) ? j : j + 1;
     const int rows3[3] = { syp - by0, sy - by0, syn - by0 };
+    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off) + loc0 * 3;
+    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off) + loc0;
+    if constexpr (F32) {
+        if (__builtin_amdgcn_ballot_w64(edge) == 0) {
+            // interior columns, packed fp32: channels (0,1) as a float2, channel 2 scalar
+            f2 heL[3], hoL[3]; float he2[3], ho2[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const float* pa = Bt[rows3[r]][j - 1].c; const float* pb = Bt[rows3[r]][j].c; const float* pc = Bt[rows3[r]][j + 1].c;
+                const f2 aL = { pa[0], pa[1] }, bL = { pb[0], pb[1] }, cL = { pc[0], pc[1] };
+                const float a2 = pa[2], b2 = pb[2], c2 = pc[2];
+                heL[r] = aL + bL * 6.f + cL; hoL[r] = (bL + cL) * 4.f;
+                he2[r] = a2 + b2 * 6 + c2;   ho2[r] = (b2 + c2) * 4;
+            }
+            const f2 g00L = { g00.c[0], g00.c[1] }, g01L = { g01.c[0], g01.c[1] }, g10L = { g10.c[0], g10.c[1] }, g11L = { g11.c[0], g11.c[1] };
+            const f2 o00L = g00L - (heL[0] + heL[1] * 6.f + heL[2]) * (1.f / 64);
+            const f2 o01L = g01L - (hoL[0] + hoL[1] * 6.f + hoL[2]) * (1.f / 64);
+            const f2 o10L = g10L - ((heL[1] + heL[2]) * 4.f) * (1.f / 64);
+            const f2 o11L = g11L - ((hoL[1] + hoL[2]) * 4.f) * (1.f / 64);
+            const float o00c = g00.c[2] - (he2[0] + he2[1] * 6 + he2[2]) * (1.f / 64);
+            const float o01c = g01.c[2] - (ho2[0] + ho2[1] * 6 + ho2[2]) * (1.f / 64);
+            const float o10c = g10.c[2] - ((he2[1] + he2[2]) * 4) * (1.f / 64);
+            const float o11c = g11.c[2] - ((ho2[1] + ho2[2]) * 4) * (1.f / 64);
+            if (s00) { dl[0] = o00L.x; dl[1] = o00L.y; dl[2] = o00c; dw[0] = g00.w; }
+            if (s01) { dl[3] = o01L.x; dl[4] = o01L.y; dl[5] = o01c; dw[1] = g01.w; }
+            if (s10) { dl[3 * ts] = o10L.x; dl[3 * ts + 1] = o10L.y; dl[3 * ts + 2] = o10c; dw[ts] = g10.w; }
+            if (s11) { dl[3 * ts + 3] = o11L.x; dl[3 * ts + 4] = o11L.y; dl[3 * ts + 5] = o11c; dw[ts + 1] = g11.w; }
+            return;
+        }
+    }
     WT he[3][3], ho[3][3];                                   // [row][channel]: even / odd output column
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -881,8 +956,6 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
             }
         }
     }
-    T PF_GLOBAL* dl = (T PF_GLOBAL*)(slot + lay.lap_off) + loc0 * 3;
-    float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + lay.w_off) + loc0;
     T o00[3], o01[3], o10[3], o11[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
