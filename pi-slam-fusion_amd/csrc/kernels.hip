@@ -346,17 +346,32 @@ __device__ __forceinline__ double rcp_mid_range(double d)
     return __builtin_fma(rem, r, r);
 }
 
-// one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
-template <bool F32>
-__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const FusedWarp& a, int x, int y)
+// the terms of the coordinate that depend on the canvas column only: xb = x & ~63 is OpenCV's 64-wide
+// coordinate block, x1 = x & 63 the offset inside it
+struct WarpCol { double m0xb, m3xb, m6xb, m0x1, m3x1, m6x1; };
+__device__ __forceinline__ WarpCol warp_col(const FusedWarp& a, int x)
 {
-    PxT<F32> o;
-    const int xb = x & ~63, x1 = x & 63;                     // OpenCV's 64-wide coordinate block
-    const double X0 = a.M[0] * xb + a.M[1] * y + a.M[2];
-    const double Y0 = a.M[3] * xb + a.M[4] * y + a.M[5];
-    const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
-    const double W  = W0 + a.M[6] * x1;
-    const double xn = X0 + a.M[0] * x1, yn = Y0 + a.M[3] * x1;
+    const int xb = x & ~63, x1 = x & 63;
+    return { a.M[0] * xb, a.M[3] * xb, a.M[6] * xb, a.M[0] * x1, a.M[3] * x1, a.M[6] * x1 };
+}
+
+// A warped pixel is produced in two steps so that a thread can have the loads of its next pixel in flight
+// while it finishes the current one: warp_fetch (coordinates, border mapping, exactly three loads, no load
+// under divergent control flow) and warp_finish (tap extraction, bilinear sum).
+struct WarpTaps {
+    uint32_t lo0, hi0, lo1, hi1;     // 8 bytes of each of the two source rows
+    float    wraw;                   // weight plane entry (valid when kInb is set)
+    uint32_t meta;                   // X&31 | (Y&31)<<5 | flags<<10
+};
+constexpr uint32_t kT0Hi = 1, kT1Hi = 2, kBack0 = 2, kBack1 = 5, kInb = 1u << 8;   // flags: tap = high pixel, byte shifts, weight in bounds
+
+__device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
+{
+    const double X0 = col.m0xb + a.M[1] * y + a.M[2];
+    const double Y0 = col.m3xb + a.M[4] * y + a.M[5];
+    const double W0 = col.m6xb + a.M[7] * y + a.M[8];
+    const double W  = W0 + col.m6x1;
+    const double xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
     // nearest coordinate p = (X0+M0*x1)*(1/W); the 1/32-px coordinate (X0+M0*x1)*(32/W) equals 32*p
     // bit for bit (32/W == 32*(1/W) and scaling by a power of two commutes with rounding).
     // Common case, decided per wave: W in the mid range (reciprocal without the scale/fixup steps) and both
@@ -381,34 +396,30 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
             X = __double2int_rn(qx * 32.); Y = __double2int_rn(qy * 32.);
         }
     }
+    WarpTaps t;
+    uint32_t flags;
+    typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
     {
+        // weight: INTER_NEAREST, BORDER_CONSTANT 0 (out of bounds reads entry 0 and is zeroed in warp_finish)
         const int sx = sat_short(Xn), sy = sat_short(Yn);
-        float wv = 0.f;
-        if ((unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows) wv = *(const float*)((const char*)a.wmap + ((uint32_t)(__mul24(sy, a.scols) + sx) << 2));
-        o.w = wv;
+        const bool inb = (unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows;
+        const uint32_t woff = inb ? (uint32_t)(__mul24(sy, a.scols) + sx) << 2 : 0u;
+        t.wraw = *(const float*)((const char*)a.wmap + woff);
+        flags = inb ? kInb : 0u;
     }
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
-    const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
-    const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
-    float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
-    // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes cn..cn+2
-    // (v_perm_b32 with a per-launch selector).  Frames are < 2 GiB and rows/steps fit 24 bits: 32-bit
-    // unsigned offsets from the frame base, full-rate 24-bit multiplies.
+    // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes cn..cn+2.
+    // Frames are < 2 GiB and rows/steps fit 24 bits: 32-bit unsigned offsets from the frame base, full-rate
+    // 24-bit multiplies.
     const int cn = a.cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
-    const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;
     const uint32_t total = (uint32_t)a.total, step = (uint32_t)a.sstep;
+    uint32_t off0, off1;
     // strictly inside the frame and not on its last two rows: both 8-byte reads stay inside the buffer
     const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 2);
     if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
-        const uint32_t off0 = (uint32_t)(__mul24(sy, a.sstep) + __mul24(cn, sx));
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
-            const u2 bits = *(const u2*)(src + (j ? off0 + step : off0));
-            const uint32_t lo = bits.x, hi = __builtin_amdgcn_perm(bits.y, bits.x, hisel);
-            v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
-            v[2 * j + 1][0] = (float)(hi & 0xff); v[2 * j + 1][1] = (float)((hi >> 8) & 0xff); v[2 * j + 1][2] = (float)((hi >> 16) & 0xff);
-        }
+        off0 = (uint32_t)(__mul24(sy, a.sstep) + __mul24(cn, sx));
+        off1 = off0 + step;
+        flags |= kT1Hi;
     } else {
         int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
         if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
@@ -417,17 +428,45 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
         }
         // after BORDER_REFLECT the two taps of a row are the same or adjacent pixels
         const int xbase = sx0 < sx1 ? sx0 : sx1;
-        const bool t0hi = sx0 != xbase, t1hi = sx1 != xbase;
+        if (sx0 != xbase) flags |= kT0Hi;
+        if (sx1 != xbase) flags |= kT1Hi;
+        off0 = (uint32_t)(__mul24(sy0, a.sstep) + __mul24(cn, xbase));
+        off1 = (uint32_t)(__mul24(sy1, a.sstep) + __mul24(cn, xbase));
+        // last bytes of the frame: never read past it -- read earlier and shift
+        const uint32_t back0 = off0 + 8 > total ? off0 + 8 - total : 0u, back1 = off1 + 8 > total ? off1 + 8 - total : 0u;
+        off0 -= back0; off1 -= back1;
+        flags |= back0 << kBack0 | back1 << kBack1;
+    }
+    const u2 b0 = *(const u2*)(src + off0), b1 = *(const u2*)(src + off1);
+    t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y;
+    t.meta = (uint32_t)(X & 31) | (uint32_t)(Y & 31) << 5 | flags << 10;
+    return t;
+}
+
+template <bool F32>
+__device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
+{
+    PxT<F32> o;
+    const uint32_t flags = t.meta >> 10;
+    o.w = (flags & kInb) ? t.wraw : 0.f;
+    const float fx = (float)(t.meta & 31) * (1.f / 32), fy = (float)((t.meta >> 5) & 31) * (1.f / 32);
+    const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
+    const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;      // v_perm_b32: bytes cn..cn+3 of the 8
+    float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
+    if (__builtin_amdgcn_ballot_w64((flags & ~kInb) != kT1Hi) == 0) {
+        // whole wave strictly inside the frame: taps are (lo, hi) of each row
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const uint32_t off = (uint32_t)(__mul24(j ? sy1 : sy0, a.sstep) + __mul24(cn, xbase));
-            uint64_t bits;
-            if (off + 8 > total) {           // last bytes of the frame: never read past it
-                const uint32_t back = off + 8 - total;
-                __builtin_memcpy(&bits, src + (off - back), 8);
-                bits >>= 8 * back;
-            } else
-                __builtin_memcpy(&bits, src + off, 8);
+            const uint32_t lo = j ? t.lo1 : t.lo0, hi = __builtin_amdgcn_perm(j ? t.hi1 : t.hi0, lo, hisel);
+            v[2 * j][0] = (float)(lo & 0xff); v[2 * j][1] = (float)((lo >> 8) & 0xff); v[2 * j][2] = (float)((lo >> 16) & 0xff);
+            v[2 * j + 1][0] = (float)(hi & 0xff); v[2 * j + 1][1] = (float)((hi >> 8) & 0xff); v[2 * j + 1][2] = (float)((hi >> 16) & 0xff);
+        }
+    } else {
+        const bool t0hi = flags & kT0Hi, t1hi = flags & kT1Hi;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint64_t bits = (uint64_t)(j ? t.hi1 : t.hi0) << 32 | (j ? t.lo1 : t.lo0);
+            bits >>= 8 * ((flags >> (j ? kBack1 : kBack0)) & 7);
             const uint32_t lo = (uint32_t)bits, hi = __builtin_amdgcn_perm((uint32_t)(bits >> 32), (uint32_t)bits, hisel);
             const float l0 = (float)(lo & 0xff), l1 = (float)((lo >> 8) & 0xff), l2 = (float)((lo >> 16) & 0xff);
             const float h0 = (float)(hi & 0xff), h1 = (float)((hi >> 8) & 0xff), h2 = (float)((hi >> 16) & 0xff);
@@ -442,12 +481,19 @@ __device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, 
             const float s = (float)(1. / 255.);
             v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
         }
-        const float t = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
-        if constexpr (F32) o.c[k] = t;
-        else o.c[k] = (short)sat_short(__float2int_rn(t));
+        const float tt = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+        if constexpr (F32) o.c[k] = tt;
+        else o.c[k] = (short)sat_short(__float2int_rn(tt));
     }
     if constexpr (!F32) o.pad = 0;
     return o;
+}
+
+// one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
+template <bool F32>
+__device__ __forceinline__ PxT<F32> warp_pixel(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
+{
+    return warp_finish<F32>(warp_fetch(src, a, col, y), a.cn);
 }
 
 // horizontal pyrUp term of one G_{i+1} row (pyramids.cpp pyrUp_): a,b,c = s[sx-1], s[sx], s[sx+1].
@@ -573,7 +619,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
             if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y);
+            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, warp_col(wa, x), y);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
         }
@@ -757,15 +803,30 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
 
     // ---- A
     if constexpr (FROM_WARP) {
+        // a thread keeps one column of A and walks down it LNT / LAW rows at a time: the column terms of the
+        // coordinate are formed once
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
-        int r = tid / LAW, c = tid - r * LAW;
-        for (int idx = tid; idx < LAH * LAW; idx += LNT) {
-            int y = ay0 + r, x = ax0 + c;
-            if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
-            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
-            (&A[0][0])[idx] = warp_pixel<F32>(src, wa, x, y);
-            c += LNT % LAW; r += LNT / LAW;
-            if (c >= LAW) { c -= LAW; r++; }
+        constexpr int RS = LNT / LAW;
+        const int r0 = tid / LAW, c = tid - r0 * LAW;
+        if (r0 < RS) {
+            int x = ax0 + c;
+            if (!inner) x = border_reflect101(x, g.cols);
+            const WarpCol col = warp_col(wa, x);
+            // two rows per step: the second pixel's coordinates and loads overlap the first one's loads
+            for (int r = r0; r < LAH; r += 2 * RS) {
+                const int rb = r + RS;
+                const bool hasb = rb < LAH;
+                int y = ay0 + r, yb = ay0 + rb;
+                if (!inner) { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
+                if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; if (hasb) A[rb][c] = z; continue; }
+                const WarpTaps ta = warp_fetch(src, wa, col, y);
+                if (__builtin_amdgcn_ballot_w64(hasb) != 0) {
+                    const WarpTaps tb = warp_fetch(src, wa, col, hasb ? yb : y);
+                    A[r][c] = warp_finish<F32>(ta, wa.cn);
+                    if (hasb) A[rb][c] = warp_finish<F32>(tb, wa.cn);
+                } else
+                    A[r][c] = warp_finish<F32>(ta, wa.cn);
+            }
         }
     } else {
         stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
