@@ -850,7 +850,10 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
 
     // ---- B: two vertically adjacent outputs per thread
     const int vec_img = (ncols * 3 / 8) * 8, vec_w = (ncols / 8) * 8;     // PyrDownVec_32f coverage
-    for (int idx = tid; idx < (LQH / 2) * LQW; idx += LNT) {
+    // the (LQH/2)*LQW work items go to the LAST threads of the workgroup: stage A gives the first waves one
+    // more pixel per lane than the last ones, so this evens out the per-SIMD load
+    static_assert((LQH / 2) * LQW <= LNT, "one B item per thread at most");
+    for (int idx = tid - (LNT - (LQH / 2) * LQW); idx >= 0 && idx < (LQH / 2) * LQW; idx += LNT) {
         const int pp = idx / LQW, q = idx - pp * LQW;
         const int X = bx0 + q;
         if (X < 0 || X >= ncols) continue;
