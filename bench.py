@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="Map2D.Scale (1 = cfg-A, 0.5 = shipped Default.cfg)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames kept in HBM")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="HIP events around every n-th launch of the dominant kernel in the timed region "
+                         "(each event pair costs stream time; 0 = none, no roofline)")
     args = ap.parse_args()
 
     import torch
@@ -200,7 +203,8 @@ def main():
     names = list(prof.keys())
     dom = max(names, key=lambda n: prof[n]["ms"]) if W > 0 else "warp"
     m.profile_reset()
-    m.profile_enable(2 + names.index(dom))          # timed region: events around that kernel only
+    # timed region: events around that kernel only, every n-th launch
+    m.profile_enable((2 + names.index(dom)) | (args.event_every << 8) if args.event_every else 0)
 
     def barrier():
         if dist is not None:
@@ -247,7 +251,7 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "avg_launch_us": round(p["ms"] / max(p["launches"], 1) * 1e3, 2),
                          "alg_bytes_per_launch": round(p["alg_bytes"] / max(p["launches"], 1)),
-                         "launches": p["launches"]},
+                         "launches": p["launches"], "timed_every": args.event_every},
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (N * K / dt) / N / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in names if prof[n]["launches"]},
         }

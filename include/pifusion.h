@@ -52,9 +52,11 @@ typedef struct pf_options {
     int    shard_count;      /* ... of shard_count (1 = own every tile)      */
     int    shard_block;      /* spatial-hash cell edge in tiles (default 8)  */
     int    max_queue;        /* feed queue cap, drop-oldest (20)    .cpp:302 */
-    int    fused;            /* 1 (default): fused per-level kernels; 2: the same in the
-                                4-stage 64x16-block shape; 0: one kernel per reference
-                                op (warp / pyrDown / Laplacian+select)               */
+    int    fused;            /* fused level kernels.  1 (default): one launch per keyframe,
+                                levels pipelined across frames; 3: one launch and stream
+                                per level; 2: as 3 in the 4-stage 64x16-block shape;
+                                0: one kernel per reference op (warp / pyrDown /
+                                Laplacian+select)                                    */
 } pf_options;
 
 typedef struct pf_map pf_map;
@@ -151,7 +153,9 @@ int     pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in);
 
 /* --- measurement -------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the map's own stream.  mode 0 = off,
- * 1 = every kernel, 2+k = only kernel k (index in pf_profile_read order).  Read returns count kernels; name[i] static strings.   */
+ * 1 = every kernel, 2+k = only kernel k (index in pf_profile_read order); adding n << 8 times every
+ * n-th launch only (an event pair costs a few microseconds of stream time per launch).  Read returns
+ * the kernel count; names[i] are static strings; ms / launches / bytes cover the timed launches.    */
 int     pf_profile_enable(pf_map* m, int mode);
 int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
                         double* alg_bytes);

@@ -121,7 +121,9 @@ FusionMap::~FusionMap()
     prof_harvest();
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
     for (int i = 0; i < kMaxLevels; i++) {
-        if (i > 0 && lvl_stream_[i] && lvl_stream_[i] != stream_) (void)hipStreamDestroy(lvl_stream_[i]);
+        bool shared = lvl_stream_[i] == stream_;
+        for (int k = 1; k < i; k++) shared = shared || lvl_stream_[k] == lvl_stream_[i];
+        if (i > 0 && lvl_stream_[i] && !shared) (void)hipStreamDestroy(lvl_stream_[i]);
         for (int k = 0; k < kTableRing; k++) if (lvl_ev_[i][k]) (void)hipEventDestroy(lvl_ev_[i][k]);
         gw_[i].release(); gw2_[i].release();
     }
@@ -144,6 +146,7 @@ bool FusionMap::set_device() { HIP_OK(hipSetDevice(device_)); return true; }
 // per-level streams of the fused pipeline
 hipError_t FusionMap::sync_all()
 {
+    if (!flush_pipeline()) return hipErrorUnknown;
     hipError_t e = hipStreamSynchronize(stream_);
     for (int i = 1; i < kMaxLevels; i++)
         if (lvl_stream_[i] && lvl_stream_[i] != stream_) { hipError_t e2 = hipStreamSynchronize(lvl_stream_[i]); if (e == hipSuccess) e = e2; }
@@ -156,7 +159,10 @@ void FusionMap::profile_enable(int mode) { std::lock_guard<std::mutex> l(mu_); p
 void FusionMap::prof_begin(int id, double bytes, hipStream_t st)
 {
     prof_stream_ = st ? st : stream_;
-    prof_on_ = prof_mode_ == 1 || prof_mode_ == 2 + id;      // mode 2+k: only kernel k
+    const int what = prof_mode_ & 0xff, every = prof_mode_ >> 8;
+    prof_on_ = what == 1 || what == 2 + id;                  // mode 2+k: only kernel k
+    // event pairs are not free (each is a marker packet between two launches): optionally time every n-th launch only
+    if (prof_on_ && every > 1) prof_on_ = (prof_tick_[id]++ % every) == 0;
     if (!prof_on_) return;
     auto get = [&]() { hipEvent_t e; if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); } else (void)hipEventCreate(&e); return e; };
     prof_cur_ = { id, get(), get(), bytes };
@@ -200,7 +206,7 @@ void FusionMap::profile_reset()
     (void)hipSetDevice(device_);
     (void)sync_all();
     prof_harvest();
-    for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; }
+    for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; prof_tick_[i] = 0; }
 }
 
 void FusionMap::stats(long long* rendered, long long* rejected, long long* dropped)
@@ -495,7 +501,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
 
     // per-level windows: Gaussian level i must be valid on need[i] so that the
     // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
-    struct Win { int x0, x1, y0, y1; } need[kMaxLevels];
+    Win need[kMaxLevels];
     auto clampw = [](int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); };
     for (int i = L; i >= 0; i--) {
         const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
@@ -561,8 +567,6 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             tab[y * tx + x] = ent;
         }
     HIP_OK(hipMemcpyAsync(table_dev_[ring].p, tab, (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
-    HIP_OK(hipEventRecord(table_ev_[ring], stream_));
-    table_pending_[ring] = true;
     const uint64_t* dtab = (const uint64_t*)table_dev_[ring].p;
 
     // warp (.cpp:443-452)
@@ -599,7 +603,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         a.wmap = (const float*)wmap_.p;
         // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
-        struct Win C[kMaxLevels];
+        Win C[kMaxLevels];
         for (int i = L - 1; i >= 0; i--) {
             const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
             int x0 = bx0 * ts, x1 = bx1 * ts, y0 = by0 * ts, y1 = by1 * ts;
@@ -610,18 +614,33 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             clampw(x0, x1, cols, C[i].x0, C[i].x1);
             clampw(y0, y1, rows, C[i].y0, C[i].y1);
         }
-        // One stream per level: level i of frame f runs after level i-1 of frame f (GW_i) and, by
-        // stream order, after level i of frame f-1 (tiles are updated in feed order).  The small
-        // upper levels of frame f thus overlap the level-0 kernel of frame f+1.  GW buffers are
-        // double-buffered by frame parity; a writer waits for the reader two frames back.
         const double E = 3 * es + 4;
+        if (opt_.fused == 1) {
+            // one launch per keyframe: this frame's level 0 plus the pending upper levels of the frames before it
+            PipeFrame cur;
+            cur.valid = true; cur.ring = ring; cur.tx = tx; cur.crows = crows; cur.ccols = ccols;
+            for (int i = 0; i < L; i++) {
+                cur.C[i] = C[i];
+                const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
+                // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
+                cur.bytes[i] = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0) + (i == 0 ? (double)a.src_cn * f.rows * f.cols : 0);
+            }
+            if (!launch_pipeline(&cur, &a, src)) return false;
+        } else {
+        // fused = 2 / 3: one launch per level and one stream per level.  Level i of frame f runs after level i-1
+        // of frame f (GW_i) and, by
         const unsigned long long fidx = frame_seq_ - 1;
         const int slot = (int)(fidx % kTableRing);
         DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
         for (int i = 0; i < L; i++) {
             if (!lvl_stream_[i]) {
+                // HIP multiplexes streams onto a few hardware queues (4 by default), and streams that share one
+                // serialize: keep the count small.  Level 0 has its own stream, the upper levels -- a dependent
+                // chain within a frame anyway -- share kUpperStreams (PF_LEVEL_STREAMS, diagnostics).
+                static const int n_upper = std::getenv("PF_LEVEL_STREAMS") ? std::atoi(std::getenv("PF_LEVEL_STREAMS")) : kUpperStreams;
                 if (i == 0) lvl_stream_[0] = stream_;
-                else if (std::getenv("PF_SINGLE_STREAM")) lvl_stream_[i] = stream_;      // diagnostics: serial kernel times
+                else if (std::getenv("PF_SINGLE_STREAM") || n_upper <= 0) lvl_stream_[i] = stream_;      // diagnostics: serial kernel times
+                else if (i > n_upper) lvl_stream_[i] = lvl_stream_[1 + (i - 1) % n_upper];
                 else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
             }
             for (int k = 0; k < kTableRing; k++)
@@ -638,12 +657,14 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             if (i == 0) bytes += (double)a.src_cn * f.rows * f.cols;
             prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
             launch_level(st, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
-                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab, opt_.fused);
+                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab, opt_.fused);   // 2: 4-stage k_level, 3: k_level3
             prof_end();
             HIP_OK(hipEventRecord(lvl_ev_[i][slot], st));
         }
         // the tile table of this ring slot is read until the last level has run
         HIP_OK(hipEventRecord(table_ev_[ring], lvl_stream_[L - 1]));
+        table_pending_[ring] = true;
+        }
     } else {
     const double win0 = (double)a.wrows * a.wcols;
     prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
@@ -671,10 +692,66 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     }
     }
     HIP_OK(hipGetLastError());
+    if (!table_pending_[ring] && !(fused && opt_.fused == 1)) { HIP_OK(hipEventRecord(table_ev_[ring], stream_)); table_pending_[ring] = true; }   // last reader of the table
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
     for (Tile* t : touched) { t->fresh = false; t->changed = true; }
     n_rendered_++;
     return true;
+}
+
+// One pipelined launch (kernels.hip, k_levels): level 0 of `cur` (if any) and level s of pipe_[s] for every
+// pending frame.  A job at level s reads GW_s from the buffer set the previous launch wrote and writes
+// GW_{s+1} into this launch's set; stream order between launches is the only synchronisation.
+bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const uint8_t* src)
+{
+    const int L = band_num_;
+    const int par = (int)(launch_seq_ & 1);
+    DevBuf* out = par ? gw2_ : gw_;
+    DevBuf* in  = par ? gw_ : gw2_;
+    LevelLaunch jobs[kMaxLevels];
+    int n = 0;
+    double bytes = 0;
+    auto add = [&](const PipeFrame& fr, int i) {
+        const bool top = (i + 1 == L);
+        LevelLaunch& q = jobs[n++];
+        q.level = i; q.rows = fr.crows >> i; q.cols = fr.ccols >> i;
+        q.cx0 = fr.C[i].x0; q.cy0 = fr.C[i].y0; q.cx1 = fr.C[i].x1; q.cy1 = fr.C[i].y1;
+        q.tiles_x = fr.tx; q.top_select = top; q.write_next = !top; q.from_warp = (i == 0);
+        q.gw_in = i == 0 ? nullptr : in[i].p; q.gw_out = top ? nullptr : out[i + 1].p;
+        q.table = (const uint64_t*)table_dev_[fr.ring].p;
+        bytes += fr.bytes[i];
+    };
+    for (int s = L - 1; s >= 1; s--) if (pipe_[s].valid) add(pipe_[s], s);       // smallest jobs first
+    if (cur) add(*cur, 0);
+    if (n) {
+        prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_);
+        launch_levels(stream_, lay_, jobs, n, wa, src);
+        prof_end();
+        HIP_OK(hipGetLastError());
+    }
+    // the frame whose last level just ran (this frame itself when L == 1) no longer needs its tile table
+    const PipeFrame* done = L >= 2 ? (pipe_[L - 1].valid ? &pipe_[L - 1] : nullptr) : cur;
+    if (done) { HIP_OK(hipEventRecord(table_ev_[done->ring], stream_)); table_pending_[done->ring] = true; }
+    for (int s = L - 1; s >= 2; s--) pipe_[s] = pipe_[s - 1];
+    if (L >= 2) { if (cur) pipe_[1] = *cur; else pipe_[1].valid = false; }
+    launch_seq_++;
+    return true;
+}
+
+// run the upper levels still pending for the frames fed so far (at most L-1 small launches)
+bool FusionMap::flush_pipeline()
+{
+    if (flushing_) return true;
+    flushing_ = true;
+    bool ok = true;
+    for (;;) {
+        bool any = false;
+        for (int s = 1; s < kMaxLevels; s++) any = any || pipe_[s].valid;
+        if (!any) break;
+        if (!launch_pipeline(nullptr, nullptr, nullptr)) { ok = false; break; }
+    }
+    flushing_ = false;
+    return ok;
 }
 
 // ------------------------------------------------------------ tile access

@@ -138,15 +138,25 @@ private:
     // per-frame workspace (grow-only)
     DevBuf g_[kMaxLevels], wgt_[kMaxLevels], gw_[kMaxLevels], gw2_[kMaxLevels];
     hipStream_t lvl_stream_[kMaxLevels]{};          // fused pipeline: one stream per level ([0] aliases stream_)
-    hipEvent_t  lvl_ev_[kMaxLevels][8]{};           // level i of the frame in ring slot k has run
+    static constexpr int kTableRing = 16;           // > pipeline depth (kMaxLevels)
+    hipEvent_t  lvl_ev_[kMaxLevels][kTableRing]{};  // level i of the frame in ring slot k has run
     hipStream_t prof_stream_ = nullptr;
-    static constexpr int kTableRing = 8;
+    static constexpr int kUpperStreams = 1;         // streams shared by pyramid levels >= 1
     uint64_t*  table_host_[kTableRing]{};
     DevBuf     table_dev_[kTableRing];
     size_t     table_cap_ = 0;
-    hipEvent_t table_ev_[kTableRing]{};
+    hipEvent_t table_ev_[kTableRing]{};             // last reader of the ring slot done
     bool       table_pending_[kTableRing]{};
     unsigned long long frame_seq_ = 0;
+
+    // pipelined level launches (opt_.fused == 1): pipe_[s] is the frame whose level s runs in the next launch
+    struct Win { int x0, x1, y0, y1; };
+    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels]; };
+    PipeFrame pipe_[kMaxLevels];
+    unsigned long long launch_seq_ = 0;             // parity selects the GW buffer set a launch writes
+    bool flushing_ = false;
+    bool launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const uint8_t* src);
+    bool flush_pipeline();
 
     // blend / save scratch
     DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_;
@@ -162,6 +172,7 @@ private:
     // profile
     struct ProfRec { int id; hipEvent_t a, b; double bytes; };
     int prof_mode_ = 0; bool prof_on_ = false;
+    unsigned prof_tick_[K_COUNT]{};
     std::vector<ProfRec> prof_pending_;
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};

@@ -766,10 +766,10 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
 //      serves the four pyrUp parities; one tile-table entry and two 8-byte weight loads per
 //      thread, prefetched after A
 // LDS: A + B only (54 KB fp32 / 40.6 KB int16).
-template <bool F32, bool FROM_WARP, int LBH, int LNT>
-__global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g, FusedWarp wa, const uint8_t* __restrict__ src,
-                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
-                                                 const uint64_t* __restrict__ table)
+template <bool F32, int LBH, int LNT>
+__device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
+                                             const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
+                                             PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table, const int b)
 {
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
@@ -782,12 +782,6 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     // workgroups per CU, int16 under 32 for four
     static_assert(sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget");
 
-    const int nblk = g.nbx * g.nby;
-    int b = blockIdx.x;
-    {
-        const int per = nblk >> 3;
-        if (per > 0 && b < per * 8) b = (b & 7) * per + (b >> 3);
-    }
     const int bx = b % g.nbx, by = b / g.nbx;
     const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
     const int ax0 = x0 - 4, ay0 = y0 - 4;
@@ -802,7 +796,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     uint64_t ent = (dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
 
     // ---- A
-    if constexpr (FROM_WARP) {
+    if (FROM_WARP) {
         // a thread keeps one column of A and walks down it LNT / LAW rows at a time: the column terms of the
         // coordinate are formed once
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
@@ -1034,6 +1028,51 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
     if (s11) { dl[3 * ts + 3] = o11[0]; dl[3 * ts + 4] = o11[1]; dl[3 * ts + 5] = o11[2]; dw[ts + 1] = g11.w; }
 }
 
+// XCD-aware block order: consecutive block ids go round-robin to the 8 XCDs, so block id b is mapped
+// to (b & 7) * per + (b >> 3): each XCD (own L2) works on a contiguous run of blocks
+__device__ __forceinline__ int xcd_order(int b, int nblk)
+{
+    const int per = nblk >> 3;
+    return (per > 0 && b < per * 8) ? (b & 7) * per + (b >> 3) : b;
+}
+
+// one pyramid level of one frame per launch (pf_options.fused = 3)
+template <bool F32, bool FROM_WARP, int LBH, int LNT>
+__global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g, FusedWarp wa, const uint8_t* __restrict__ src,
+                                                 const PxT<F32>* __restrict__ gw_in, PxT<F32>* __restrict__ gw_out,
+                                                 const uint64_t* __restrict__ table)
+{
+    level3_block<F32, LBH, LNT>(FROM_WARP, lay, g, wa, src, gw_in, gw_out, table, xcd_order(blockIdx.x, g.nbx * g.nby));
+}
+
+// k_levels: one launch per keyframe carrying level 0 of frame f, level 1 of frame f-1, ... level L-1 of
+// frame f-L+1 (pf_options.fused = 1).  The jobs of a launch are independent -- level i of a frame needs
+// GW_i, written by that frame's level i-1 job one launch earlier -- so the small upper levels fill the
+// chip alongside level 0 inside ONE grid, with no stream/queue multiplexing involved.  Jobs are laid out
+// smallest first; each starts at a block id that is a multiple of 8 (XCD order as above).
+struct LevelJob {
+    LevelOffsets lay;
+    LevelArgs    g;
+    const void*  gw_in;
+    void*        gw_out;
+    const uint64_t* table;     // the tile table of the job's frame
+    int first;                 // first block id
+    int from_warp;             // level 0: stage A is the warp of the launch's frame
+};
+struct LevelBatch { int njobs; LevelJob job[kMaxLevels]; };
+
+template <bool F32, int LBH, int LNT>
+__global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src)
+{
+    int j = 0;
+    for (int k = 1; k < batch.njobs; k++) if ((int)blockIdx.x >= batch.job[k].first) j = k;
+    const LevelJob& J = batch.job[j];
+    const int nblk = J.g.nbx * J.g.nby, b = (int)blockIdx.x - J.first;
+    if (b >= nblk) return;                                     // padding up to the next multiple of 8
+    level3_block<F32, LBH, LNT>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
+                                J.table, xcd_order(b, nblk));
+}
+
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
@@ -1072,6 +1111,37 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
         else         { if (wa) PF_LAUNCH(k_level3, false, true, 32, 512); else PF_LAUNCH(k_level3, false, false, 32, 512); }
     }
 #undef PF_LAUNCH
+}
+
+
+void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
+{
+    static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
+    constexpr int BH = 32;
+    LevelBatch batch{};
+    int nblocks = 0;
+    for (int k = 0; k < njobs; k++) {
+        const LevelLaunch& q = jobs[k];
+        LevelJob& J = batch.job[batch.njobs];
+        J.g.level = q.level; J.g.rows = q.rows; J.g.cols = q.cols; J.g.cx0 = q.cx0; J.g.cy0 = q.cy0; J.g.cx1 = q.cx1; J.g.cy1 = q.cy1;
+        J.g.tiles_x = q.tiles_x; J.g.top_select = q.top_select; J.g.write_next = q.write_next; J.g.ablate = ablate;
+        J.g.nbx = (q.cx1 - q.cx0 + LBW - 1) / LBW; J.g.nby = (q.cy1 - q.cy0 + BH - 1) / BH;
+        if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
+        J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
+        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
+        J.first = nblocks;
+        nblocks += (J.g.nbx * J.g.nby + 7) & ~7;
+        batch.njobs++;
+    }
+    if (!batch.njobs) return;
+    FusedWarp w{};
+    if (wa) {
+        for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
+        w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
+        w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
+    }
+    if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
+    else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
 }
 
 // ------------------------------------------------------------------ blend

@@ -72,7 +72,19 @@ void launch_lap_select(hipStream_t s, const TileLayout& lay, int level, const vo
 size_t level_px_bytes(bool f32);
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
                   int tiles_x, bool top_select, bool write_next, const WarpArgs* wa, const uint8_t* src,
-                  const void* gw_in, void* gw_out, const uint64_t* table, int shape = 1);   // shape 2: 4-stage k_level
+                  const void* gw_in, void* gw_out, const uint64_t* table, int shape = 3);   // shape 2: 4-stage k_level, 3: k_level3
+
+// Pipelined form of the same kernel: ONE launch carries several independent level jobs (level 0 of the
+// newest frame, level 1 of the frame before it, ...), each with its own tile table and GW buffers.
+struct LevelLaunch {
+    int level, rows, cols;          // pyramid level and its canvas extent
+    int cx0, cy0, cx1, cy1;         // compute region
+    int tiles_x;
+    bool top_select, write_next, from_warp;
+    const void* gw_in; void* gw_out;
+    const uint64_t* table;
+};
+void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
 void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,

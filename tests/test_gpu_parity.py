@@ -27,7 +27,7 @@ def run_pair(pf, orc, cam, poses, frames, n_prepare=None, **opt):
     return g, o
 
 
-@pytest.mark.parametrize("fused", [1, 2, 0])
+@pytest.mark.parametrize("fused", [1, 2, 3, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
 @pytest.mark.parametrize("content", ["noise", "smooth"])
 def test_cfg1_plumbing(pf, orc, force_float, content, fused):
@@ -40,7 +40,7 @@ def test_cfg1_plumbing(pf, orc, force_float, content, fused):
     assert compare_maps(g, o) == []
 
 
-@pytest.mark.parametrize("fused", [1, 2, 0])
+@pytest.mark.parametrize("fused", [1, 2, 3, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
 @pytest.mark.parametrize("bands", [0, 1, 3, 5, 7, 8])
 def test_perspective_and_spread(pf, orc, force_float, bands, fused):
@@ -177,7 +177,7 @@ def test_device_resident_feed_and_idempotence(pf):
     assert map_digest(a) == da
 
 
-@pytest.mark.parametrize("fused", [1, 2, 0])
+@pytest.mark.parametrize("fused", [1, 2, 3, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
 def test_full_size_frame_against_oracle(pf, orc, force_float, fused):
     """BASELINE.json configs[1] geometry: one 4000x3000 frame, 5 bands, vs the oracle (seconds on CPU)."""

@@ -26,7 +26,7 @@ def build(pf, cam, poses, frames, n, block, force_float, fused=1, **kw):
     return maps
 
 
-@pytest.mark.parametrize("fused", [1, 2, 0])
+@pytest.mark.parametrize("fused", [1, 2, 3, 0])
 @pytest.mark.parametrize("force_float", [0, 1])
 @pytest.mark.parametrize("block", [1, 2])
 def test_shards_union_equals_unsharded(pf, force_float, block, fused):
