@@ -721,8 +721,9 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.table = (const uint64_t*)table_dev_[fr.ring].p;
         bytes += fr.bytes[i];
     };
-    for (int s = L - 1; s >= 1; s--) if (pipe_[s].valid) add(pipe_[s], s);       // smallest jobs first
+    // level 0 first: the short upper-level blocks come last and fill the tail of the grid
     if (cur) add(*cur, 0);
+    for (int s = 1; s < L; s++) if (pipe_[s].valid) add(pipe_[s], s);
     if (n) {
         prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_);
         launch_levels(stream_, lay_, jobs, n, wa, src);

@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
 // frame f-L+1 (pf_options.fused = 1).  The jobs of a launch are independent -- level i of a frame needs
 // GW_i, written by that frame's level i-1 job one launch earlier -- so the small upper levels fill the
 // chip alongside level 0 inside ONE grid, with no stream/queue multiplexing involved.  Jobs are laid out
-// smallest first; each starts at a block id that is a multiple of 8 (XCD order as above).
+// level 0 first (the short upper-level blocks fill the tail); each starts at a block id that is a multiple of 8.
 struct LevelJob {
     LevelOffsets lay;
     LevelArgs    g;

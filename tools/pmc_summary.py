@@ -24,6 +24,8 @@ SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_py
 
 
 def short(name):
+    if "k_levels<" in name:          # pipelined launch: level 0 of a frame + upper levels of earlier frames
+        return "level0_fused"
     m = re.search(r"k_level3?<(\w+), (\w+)", name)
     if m:
         return "level0_fused" if m.group(2) == "true" else "level_fused"
@@ -50,14 +52,20 @@ def stats(d):
               float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 
 
+def counter_rows(d):
+    """rows of a --pmc pass; the pipelined k_levels launches are kept only at full size (a keyframe's launch), not
+    the short flush launches before a sync that carry upper levels only -- the same launches bench.py times"""
+    rows = [r for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))) if short(r["Kernel_Name"])]
+    full = max([int(r["Grid_Size"]) for r in rows if "k_levels<" in r["Kernel_Name"]] or [0])
+    return [r for r in rows if "k_levels<" not in r["Kernel_Name"] or int(r["Grid_Size"]) * 2 > full]
+
+
 def counter_means(d, counter):
     acc = defaultdict(list)
-    for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+    for r in counter_rows(d):
         if r["Counter_Name"] != counter:
             continue
-        s = short(r["Kernel_Name"])
-        if s:
-            acc[s].append(float(r["Counter_Value"]))
+        acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
@@ -80,10 +88,8 @@ def counters(dirs):
     """mean per launch of every counter found in the given --pmc output dirs, per kernel"""
     acc = defaultdict(lambda: defaultdict(list))
     for d in dirs:
-        for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
-            s = short(r["Kernel_Name"])
-            if s:
-                acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for r in counter_rows(d):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k in sorted(acc):
         print("## %s" % k)
         for c in sorted(acc[k]):
