@@ -14,6 +14,7 @@
 //   k_mosaic_gather / k_save_finish  :806-840 save
 #include "kernels.hpp"
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 
 namespace pf {
@@ -322,6 +323,9 @@ struct FusedWarp {
     long   total;           // bytes in the frame (srows * sstep)
     const float* wmap;      // srows x scols radial weight plane (the reference's weightImage)
     int    srows, scols, sstep, cn;
+    int    plain;           // host-checked: |M| entries < 2^400 and the frame is at most 32767 px on a side, so W
+                            // cannot leave the mid range upwards and saturate_cast<short> never alters an
+                            // in-frame coordinate (0: every pixel takes the general forms)
 };
 
 struct LevelArgs {
@@ -361,7 +365,8 @@ __device__ __forceinline__ WarpCol warp_col(const FusedWarp& a, int x)
 struct WarpTaps {
     uint32_t lo0, hi0, lo1, hi1;     // 8 bytes of each of the two source rows
     float    wraw;                   // weight plane entry (valid when kInb is set)
-    uint32_t meta;                   // X&31 | (Y&31)<<5 | flags<<10
+    int      X, Y;                   // 1/32-px source coordinate (the low 5 bits are the bilinear fractions)
+    uint32_t flags;
 };
 constexpr uint32_t kT0Hi = 1, kT1Hi = 2, kBack0 = 2, kBack1 = 5, kInb = 1u << 8;   // flags: tap = high pixel, byte shifts, weight in bounds
 
@@ -380,10 +385,12 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     // v_cvt_i32_f64 saturates, which is exactly clamp-to-int-range followed by cvRound.
     int Xn, Yn, X, Y;
     {
+        // |W| < 2^-500 (W == 0 included) ends in a huge or NaN product and fails the range test by itself;
+        // the upper end is excluded on the host (a.plain)
         const double Wn = rcp_mid_range(W);
         const double pxn = xn * Wn, pyn = yn * Wn;
-        const bool tame = fabs(W) > 0x1p-500 && fabs(W) < 0x1p500 && fabs(pxn) < 3.0e7 && fabs(pyn) < 3.0e7;
-        if (__builtin_amdgcn_ballot_w64(!tame) == 0) {
+        const bool tame = fabs(pxn) < 3.0e7 && fabs(pyn) < 3.0e7;
+        if (a.plain && __builtin_amdgcn_ballot_w64(!tame) == 0) {
             constexpr double kMagic = 6755399441055744.0;
             Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
             Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
@@ -400,14 +407,15 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     uint32_t flags;
     typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
     {
-        // weight: INTER_NEAREST, BORDER_CONSTANT 0 (out of bounds reads entry 0 and is zeroed in warp_finish)
-        const int sx = sat_short(Xn), sy = sat_short(Yn);
+        // weight: INTER_NEAREST, BORDER_CONSTANT 0 (out of bounds reads entry 0 and is zeroed in warp_finish).
+        // remap's saturate_cast<short> of the coordinate only matters for frames wider than a short.
+        int sx = Xn, sy = Yn;
+        if (!a.plain) { sx = sat_short(sx); sy = sat_short(sy); }
         const bool inb = (unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows;
         const uint32_t woff = inb ? (uint32_t)(__mul24(sy, a.scols) + sx) << 2 : 0u;
         t.wraw = *(const float*)((const char*)a.wmap + woff);
         flags = inb ? kInb : 0u;
     }
-    const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes cn..cn+2.
     // Frames are < 2 GiB and rows/steps fit 24 bits: 32-bit unsigned offsets from the frame base, full-rate
     // 24-bit multiplies.
@@ -415,12 +423,14 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     const uint32_t total = (uint32_t)a.total, step = (uint32_t)a.sstep;
     uint32_t off0, off1;
     // strictly inside the frame and not on its last two rows: both 8-byte reads stay inside the buffer
-    const bool fast = (unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 2);
-    if (__builtin_amdgcn_ballot_w64(!fast) == 0) {
-        off0 = (uint32_t)(__mul24(sy, a.sstep) + __mul24(cn, sx));
+    const int ux = X >> 5, uy = Y >> 5;
+    const bool fast = (unsigned)ux < (unsigned)(a.scols - 1) && (unsigned)uy < (unsigned)(a.srows - 2);
+    if (a.plain && __builtin_amdgcn_ballot_w64(!fast) == 0) {
+        off0 = (uint32_t)(__mul24(uy, a.sstep) + __mul24(cn, ux));
         off1 = off0 + step;
         flags |= kT1Hi;
     } else {
+        const int sx = sat_short(ux), sy = sat_short(uy);
         int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
         if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
             sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
@@ -439,7 +449,7 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     }
     const u2 b0 = *(const u2*)(src + off0), b1 = *(const u2*)(src + off1);
     t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y;
-    t.meta = (uint32_t)(X & 31) | (uint32_t)(Y & 31) << 5 | flags << 10;
+    t.X = X; t.Y = Y; t.flags = flags;
     return t;
 }
 
@@ -447,9 +457,9 @@ template <bool F32>
 __device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
 {
     PxT<F32> o;
-    const uint32_t flags = t.meta >> 10;
+    const uint32_t flags = t.flags;
     o.w = (flags & kInb) ? t.wraw : 0.f;
-    const float fx = (float)(t.meta & 31) * (1.f / 32), fy = (float)((t.meta >> 5) & 31) * (1.f / 32);
+    const float fx = (float)(t.X & 31) * (1.f / 32), fy = (float)(t.Y & 31) * (1.f / 32);
     const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
     const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;      // v_perm_b32: bytes cn..cn+3 of the 8
     float v[4][3];                           // taps (sy,sx) (sy,sx+1) (sy+1,sx) (sy+1,sx+1) after border mapping
@@ -1100,6 +1110,8 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
         w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
+        w.plain = wa->srows <= 32767 && wa->scols <= 32767;
+        for (int i = 0; i < 9; i++) if (!(std::fabs(wa->M[i]) < 0x1p400)) w.plain = 0;
     }
     LevelOffsets lo{ lay.lap_off[level], lay.w_off[level], lay.lap_off[level + 1], lay.w_off[level + 1] };
 #define PF_LAUNCH(K, F, W, ...) hipLaunchKernelGGL((K<F, W, __VA_ARGS__>), grid, dim3(512), 0, s, lo, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
@@ -1139,6 +1151,8 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
         w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
+        w.plain = wa->srows <= 32767 && wa->scols <= 32767;
+        for (int i = 0; i < 9; i++) if (!(std::fabs(wa->M[i]) < 0x1p400)) w.plain = 0;
     }
     if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
     else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
