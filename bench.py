@@ -255,6 +255,19 @@ def main():
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (N * K / dt) / N / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in names if prof[n]["launches"]},
         }
+        # measured HBM ceiling on this box: a 1 GiB device-to-device copy, read + write bytes
+        try:
+            a_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b_ = torch.empty_like(a_)
+            b_.copy_(a_); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b_.copy_(a_)
+            e1.record(); torch.cuda.synchronize()
+            out["roofline"]["copy_ceiling_GBps"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a_, b_
+        except Exception:
+            pass
         if not args.no_cpu:
             hostf = [f.cpu().numpy() for f in frames[:2]]
             out["cpu_baseline"] = cpu_baseline(wl, cam, sorties[0], prep, hostf, force_float)
