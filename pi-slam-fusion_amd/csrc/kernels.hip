@@ -38,6 +38,19 @@ __device__ __forceinline__ int border_reflect101(int p, int len)       // BORDER
     if (q < 0) q += m;
     return q < len ? q : m - q;
 }
+// the same two maps for -len <= p < 2*len (one reflection, no division): everything a canvas up to three
+// frames wide asks for.  ~p == -p-1.
+__device__ __forceinline__ bool reflect_is_near(int p, int len) { return (unsigned)(p + len) < 3u * (unsigned)len; }
+__device__ __forceinline__ int border_reflect_near(int p, int len)
+{
+    const int q = p ^ (p >> 31);
+    return min(q, 2 * len - 1 - q);
+}
+__device__ __forceinline__ int border_reflect101_near(int p, int len)
+{
+    const int q = p < 0 ? -p : p;
+    return len == 1 ? 0 : min(q, 2 * len - 2 - q);
+}
 __device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ double clamp_int_range(double v)
 {
@@ -431,8 +444,13 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
         flags |= kT1Hi;
     } else {
         const int sx = sat_short(ux), sy = sat_short(uy);
-        int sx0 = sx, sx1 = sx + 1, sy0 = sy, sy1 = sy + 1;
-        if (!((unsigned)sx < (unsigned)(a.scols - 1) && (unsigned)sy < (unsigned)(a.srows - 1))) {
+        int sx0, sx1, sy0, sy1;
+        const bool near = reflect_is_near(sx, a.scols) && reflect_is_near(sx + 1, a.scols) &&
+                          reflect_is_near(sy, a.srows) && reflect_is_near(sy + 1, a.srows);
+        if (__builtin_amdgcn_ballot_w64(!near) == 0) {        // canvas pixels next to the frame: one reflection
+            sx0 = border_reflect_near(sx, a.scols); sx1 = border_reflect_near(sx + 1, a.scols);
+            sy0 = border_reflect_near(sy, a.srows); sy1 = border_reflect_near(sy + 1, a.srows);
+        } else {
             sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
             sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
         }
@@ -814,14 +832,19 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         const int r0 = tid / LAW, c = tid - r0 * LAW;
         if (r0 < RS) {
             int x = ax0 + c;
-            if (!inner) x = border_reflect101(x, g.cols);
+            // halo coordinates lie in [-4, len + 3): one reflection unless the level is only a few pixels wide
+            const bool near101 = g.rows >= 8 && g.cols >= 8;
+            if (!inner) x = near101 ? border_reflect101_near(x, g.cols) : border_reflect101(x, g.cols);
             const WarpCol col = warp_col(wa, x);
             // two rows per step: the second pixel's coordinates and loads overlap the first one's loads
             for (int r = r0; r < LAH; r += 2 * RS) {
                 const int rb = r + RS;
                 const bool hasb = rb < LAH;
                 int y = ay0 + r, yb = ay0 + rb;
-                if (!inner) { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
+                if (!inner) {
+                    if (near101) { y = border_reflect101_near(y, g.rows); yb = border_reflect101_near(yb, g.rows); }
+                    else { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
+                }
                 if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; if (hasb) A[rb][c] = z; continue; }
                 const WarpTaps ta = warp_fetch(src, wa, col, y);
                 if (__builtin_amdgcn_ballot_w64(hasb) != 0) {
