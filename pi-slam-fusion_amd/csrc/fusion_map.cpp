@@ -334,9 +334,10 @@ int FusionMap::acquire_slot(size_t bytes)
 bool FusionMap::upload(const pf_image* img, int slot)
 {
     const size_t row = (size_t)img->cols * (img->type == PF_8UC4 ? 4 : 3), step = img->step ? img->step : row;
-    HIP_OK(hipMemcpy2DAsync(slots_[slot].dev, row, img->data, step, row, img->rows, hipMemcpyHostToDevice, copy_stream_));
-    // the caller may release its pixels when feed() returns
-    HIP_OK(hipStreamSynchronize(copy_stream_));
+    // Blocking copy: the caller may release its pixels when feed() returns, and the frame is complete in HBM
+    // before the kernel that reads it is enqueued.  The map's streams are non-blocking, so this does not wait
+    // for kernels in flight.
+    HIP_OK(hipMemcpy2D(slots_[slot].dev, row, img->data, step, row, img->rows, hipMemcpyHostToDevice));
     return true;
 }
 

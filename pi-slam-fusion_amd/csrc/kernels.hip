@@ -569,7 +569,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // stage A for levels >= 1: GW_i block + halo from HBM into LDS.  Named pixels (not an array:
 // arrays of this struct end up in scratch), four loads in flight per thread before their LDS stores.
-template <bool F32, int LAH, int LNT>
+constexpr int LAWH = (LAW + 1) / 2;                     // columns of one parity in the split layout
+
+// SPLIT: A is stored as [row][column parity][column / 2] (see level3_block)
+template <bool F32, int LAH, int LNT, bool SPLIT = false>
 __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, const PxT<F32>* __restrict__ gin,
                                                int ax0, int ay0, int rows, int cols, int tid, int begin = 0)
 {
@@ -580,15 +583,20 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
         const int y = border_reflect101(ay0 + r, rows), x = border_reflect101(ax0 + c, cols);
         return (long)y * cols + x;
     };
+    auto laddr = [&](int idx) {
+        if (!SPLIT) return idx;
+        const int r = idx / LAW, c = idx - r * LAW;
+        return r * (2 * LAWH) + (c & 1) * LAWH + (c >> 1);
+    };
 #pragma unroll
     for (int base = 0; base < LAH * LAW; base += 4 * LNT) {
         if (base + begin >= LAH * LAW) break;
         const int i0 = base + begin + tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT;
         const Px t0 = gin[gaddr(i0)], t1 = gin[gaddr(i1)], t2 = gin[gaddr(i2)], t3 = gin[gaddr(i3)];
-        if (i0 < LAH * LAW) Aflat[i0] = t0;
-        if (i1 < LAH * LAW) Aflat[i1] = t1;
-        if (i2 < LAH * LAW) Aflat[i2] = t2;
-        if (i3 < LAH * LAW) Aflat[i3] = t3;
+        if (i0 < LAH * LAW) Aflat[laddr(i0)] = t0;
+        if (i1 < LAH * LAW) Aflat[laddr(i1)] = t1;
+        if (i2 < LAH * LAW) Aflat[laddr(i2)] = t2;
+        if (i3 < LAH * LAW) Aflat[laddr(i3)] = t3;
     }
 }
 
@@ -804,8 +812,11 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
     static_assert(LNT == 32 * (LBH / 2), "one thread per 2x2 output quad");
     struct Bx { T c[F32 ? 3 : 4]; };                            // stage D needs G_{i+1} only, not W_{i+1}
-    __shared__ Px A[LAH][LAW];
+    // A is split by column parity, [row][parity][column / 2]: the pyrDown taps of neighbouring threads (2q .. 2q+4)
+    // and the 2x2 quads of stage D are then 16 bytes apart per lane instead of 32 -- no LDS bank conflicts
+    __shared__ Px A[LAH][2][LAWH];
     __shared__ Bx Bt[LQH][LQW];
+    auto Aat = [&](int r, int c) -> Px& { return A[r][c & 1][c >> 1]; };
     // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
     // workgroups per CU, int16 under 32 for four
     static_assert(sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget");
@@ -845,18 +856,18 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     if (near101) { y = border_reflect101_near(y, g.rows); yb = border_reflect101_near(yb, g.rows); }
                     else { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
                 }
-                if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); A[r][c] = z; if (hasb) A[rb][c] = z; continue; }
+                if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
                 const WarpTaps ta = warp_fetch(src, wa, col, y);
                 if (__builtin_amdgcn_ballot_w64(hasb) != 0) {
                     const WarpTaps tb = warp_fetch(src, wa, col, hasb ? yb : y);
-                    A[r][c] = warp_finish<F32>(ta, wa.cn);
-                    if (hasb) A[rb][c] = warp_finish<F32>(tb, wa.cn);
+                    Aat(r, c) = warp_finish<F32>(ta, wa.cn);
+                    if (hasb) Aat(rb, c) = warp_finish<F32>(tb, wa.cn);
                 } else
-                    A[r][c] = warp_finish<F32>(ta, wa.cn);
+                    Aat(r, c) = warp_finish<F32>(ta, wa.cn);
             }
         }
     } else {
-        stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
+        stage_from_hbm<F32, LAH, LNT, true>(&A[0][0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
     }
     lds_barrier();
     if (g.ablate & 2) return;
@@ -932,8 +943,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             };
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                const f4* row = (const f4*)&A[4 * pp + j][2 * q];
-                const f4 a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+                const f4* ev = (const f4*)&A[4 * pp + j][0][q]; const f4* od = (const f4*)&A[4 * pp + j][1][q];
+                const f4 a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
                 hl[j] = a2.xy * 6.f + (a1.xy + a3.xy) * 4.f + a0.xy + a4.xy;
                 hh[j] = a2.zw * 6.f + (a1.zw + a3.zw) * 4.f + a0.zw + a4.zw;
                 asm volatile("" : "+v"(hl[j]), "+v"(hh[j]) :: "memory");
@@ -971,8 +982,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             };
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                const Px* row = &A[4 * pp + j][2 * q];
-                const Px a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3], a4 = row[4];
+                const Px* ev = &A[4 * pp + j][0][q]; const Px* od = &A[4 * pp + j][1][q];
+                const Px a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
 #pragma unroll
                 for (int k = 0; k < 3; k++) h[j][k] = (int)a2.c[k] * 6 + ((int)a1.c[k] + (int)a3.c[k]) * 4 + (int)a0.c[k] + (int)a4.c[k];
                 hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
@@ -987,8 +998,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
 
     // ---- D: 2x2 quad, Laplacian + max-weight select
     if (!ent) return;
-    const Px g00 = A[2 * qy + 4][2 * qx + 4], g01 = A[2 * qy + 4][2 * qx + 5];
-    const Px g10 = A[2 * qy + 5][2 * qx + 4], g11 = A[2 * qy + 5][2 * qx + 5];
+    const Px g00 = A[2 * qy + 4][0][qx + 2], g01 = A[2 * qy + 4][1][qx + 2];
+    const Px g10 = A[2 * qy + 5][0][qx + 2], g11 = A[2 * qy + 5][1][qx + 2];
     const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
     const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
     const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
