@@ -333,11 +333,12 @@ int FusionMap::acquire_slot(size_t bytes)
 
 bool FusionMap::upload(const pf_image* img, int slot)
 {
+    // One linear, blocking copy of the rows as they lie in the caller's buffer (cv::Mat::step is kept: the kernels
+    // take any row step): the caller may release its pixels when feed() returns, and the frame is complete in HBM
+    // before the kernel that reads it is enqueued.  The map's streams are non-blocking, so this does not wait for
+    // kernels in flight.
     const size_t row = (size_t)img->cols * (img->type == PF_8UC4 ? 4 : 3), step = img->step ? img->step : row;
-    // Blocking copy: the caller may release its pixels when feed() returns, and the frame is complete in HBM
-    // before the kernel that reads it is enqueued.  The map's streams are non-blocking, so this does not wait
-    // for kernels in flight.
-    HIP_OK(hipMemcpy2D(slots_[slot].dev, row, img->data, step, row, img->rows, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(slots_[slot].dev, img->data, (size_t)(img->rows - 1) * step + row, hipMemcpyHostToDevice));
     return true;
 }
 
@@ -362,13 +363,18 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
                 return true;    // the threaded reference enqueues and fails later on the render thread
             }
             if (img->data) {
+                const size_t row_bytes = (size_t)img->cols * f.cn;
+                if ((img->step && img->step < row_bytes) || (img->step ? img->step : row_bytes) * (size_t)img->rows >= (1ull << 31)) {
+                    set_error("feed: row step smaller than a row, or frame of 2 GiB or more");
+                    return false;
+                }
                 if (device_ptr) {
                     if (thread_) { set_error("pf_feed_device needs a thread=0 map"); return false; }
                     f.ext = (const uint8_t*)img->data; f.step = img->step ? (long)img->step : (long)img->cols * f.cn;
                 } else {
-                    f.slot = acquire_slot((size_t)img->rows * img->cols * f.cn);
+                    f.step = img->step ? (long)img->step : (long)img->cols * f.cn;
+                    f.slot = acquire_slot((size_t)img->rows * (size_t)f.step);
                     if (f.slot < 0 || !upload(img, f.slot)) return false;
-                    f.step = (long)img->cols * f.cn;
                 }
             }
         }
