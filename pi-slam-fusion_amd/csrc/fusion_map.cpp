@@ -99,8 +99,7 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     else if (hipGetDevice(&device_) != hipSuccess) device_ = 0;
     if (device_ >= ndev) { set_error("device ordinal out of range"); return; }
     if (hipSetDevice(device_) != hipSuccess) { set_error("hipSetDevice failed"); return; }
-    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return; }
+    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return; }
     for (int i = 0; i < kTableRing; i++)
         if (hipEventCreateWithFlags(&table_ev_[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return; }
     init_ok_ = true;
@@ -117,7 +116,6 @@ FusionMap::~FusionMap()
     if (!init_ok_) return;
     (void)hipSetDevice(device_);
     (void)sync_all();
-    (void)hipStreamSynchronize(copy_stream_);
     prof_harvest();
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
     for (int i = 0; i < kMaxLevels; i++) {
@@ -137,7 +135,6 @@ FusionMap::~FusionMap()
     blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release(); wmap_.release();
     store_.clear();
     (void)hipStreamDestroy(stream_);
-    (void)hipStreamDestroy(copy_stream_);
 }
 
 bool FusionMap::set_device() { HIP_OK(hipSetDevice(device_)); return true; }

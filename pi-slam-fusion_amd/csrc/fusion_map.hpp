@@ -123,7 +123,7 @@ private:
     DevBuf     w8_; int w8_rows_ = 0, w8_cols_ = 0;   // its weight byte plane
     DevBuf     wmap_; int wmap_rows_ = 0, wmap_cols_ = 0;   // multi-band: fp32 weight plane (weightImage)
     int        device_ = 0;
-    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+    hipStream_t stream_ = nullptr;
 
     // prepared state, guarded by mu_
     std::mutex mu_;
