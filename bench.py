@@ -136,7 +136,8 @@ def main():
     m = pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt)
 
     # one sortie per rank; sortie j is flown inside a hash cell owned by rank j
-    base = wl.serpentine(cam, height, n_traj)
+    # 16 rows of 20 frames (~850 m x 400 m) fit one 128-tile hash cell; longer runs fly the sortie again
+    base = wl.serpentine(cam, height, n_traj, max_rows=16)
     if N == 1:
         prep = base[:20]
         assert m.prepare(wl.IDENTITY_PLANE, cam, prep)

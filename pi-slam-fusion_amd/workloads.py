@@ -49,9 +49,11 @@ def cfg1(n=10, step=10.0):
 
 
 def serpentine(cam, height, n_frames, per_row=20, fwd_overlap=0.8, side_overlap=0.6, seed=42,
-               yaw_jitter_deg=5.0, tilt_jitter_deg=2.0, origin=(0.0, 0.0)):
+               yaw_jitter_deg=5.0, tilt_jitter_deg=2.0, origin=(0.0, 0.0), max_rows=None):
     """cfg-2 trajectory: camera below the plane (z=-H) looking along +z, image y is
-    the flight direction; 80 % forward / 60 % side overlap, yaw +-5 deg, roll/pitch +-2 deg."""
+    the flight direction; 80 % forward / 60 % side overlap, yaw +-5 deg, roll/pitch +-2 deg.
+    max_rows: after that many rows the sortie is flown again from its first row (bounded area
+    and tile memory for long runs; every frame is still a full render)."""
     w, h, fx, fy = cam[0], cam[1], cam[2], cam[3]
     foot_x, foot_y = w * height / fx, h * height / fy
     dy, dx = foot_y * (1 - fwd_overlap), foot_x * (1 - side_overlap)
@@ -59,6 +61,8 @@ def serpentine(cam, height, n_frames, per_row=20, fwd_overlap=0.8, side_overlap=
     poses = []
     for k in range(n_frames):
         row, col = divmod(k, per_row)
+        if max_rows:
+            row %= max_rows
         if row & 1:
             col = per_row - 1 - col
         yaw = math.radians(rng.uniform(-yaw_jitter_deg, yaw_jitter_deg))
