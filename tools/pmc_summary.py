@@ -50,6 +50,24 @@ def stats(d):
         n = re.sub(r"\(.*", "", r["Name"])[:70]
         print("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (n, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
               float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+    full_launches(d)
+
+
+def full_launches(d):
+    """k_levels only: mean duration of the full-size launches (one per keyframe) from the per-dispatch trace,
+    i.e. without the short flush launches before a sync -- the launches bench.py puts its events around"""
+    try:
+        rows = [r for r in csv.DictReader(open(find(d, "*_kernel_trace.csv"))) if "k_levels<" in r["Kernel_Name"]]
+    except SystemExit:
+        return
+    if not rows:
+        return
+    size = lambda r: int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
+    full = max(size(r) for r in rows)
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if size(r) * 2 > full]
+    print()
+    print("`k_levels` full-size launches only (%d of %d dispatches): avg %.2f us, min %.2f us, max %.2f us" %
+          (len(dur), len(rows), sum(dur) / len(dur), min(dur), max(dur)))
 
 
 def counter_rows(d):
