@@ -631,8 +631,10 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             }
             if (!launch_pipeline(&cur, &a, src)) return false;
         } else {
-        // fused = 2 / 3: one launch per level and one stream per level.  Level i of frame f runs after level i-1
-        // of frame f (GW_i) and, by
+        // fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
+        // Level i of frame f runs after level i-1 of frame f (GW_i, event) and, by stream order, after level i of
+        // frame f-1 (tiles are updated in feed order).  GW buffers are double-buffered by frame parity; a writer
+        // waits for the reader two frames back.
         const unsigned long long fidx = frame_seq_ - 1;
         const int slot = (int)(fidx % kTableRing);
         DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
