@@ -1117,6 +1117,15 @@ __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp w
                                 J.table, xcd_order(b, nblk));
 }
 
+// FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
+static int plain_homography(const WarpArgs& wa)
+{
+    static const bool force_general = getenv("PF_FORCE_GENERAL") != nullptr;
+    if (force_general || wa.srows > 32767 || wa.scols > 32767) return 0;
+    for (int i = 0; i < 9; i++) if (!(std::fabs(wa.M[i]) < 0x1p400)) return 0;
+    return 1;
+}
+
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
@@ -1144,8 +1153,7 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
         w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
-        w.plain = wa->srows <= 32767 && wa->scols <= 32767;
-        for (int i = 0; i < 9; i++) if (!(std::fabs(wa->M[i]) < 0x1p400)) w.plain = 0;
+        w.plain = plain_homography(*wa);
     }
     LevelOffsets lo{ lay.lap_off[level], lay.w_off[level], lay.lap_off[level + 1], lay.w_off[level + 1] };
 #define PF_LAUNCH(K, F, W, ...) hipLaunchKernelGGL((K<F, W, __VA_ARGS__>), grid, dim3(512), 0, s, lo, g, w, src, (const PxT<F>*)gw_in, (PxT<F>*)gw_out, table)
@@ -1185,8 +1193,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
         w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
-        w.plain = wa->srows <= 32767 && wa->scols <= 32767;
-        for (int i = 0; i < 9; i++) if (!(std::fabs(wa->M[i]) < 0x1p400)) w.plain = 0;
+        w.plain = plain_homography(*wa);
     }
     if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
     else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);

@@ -236,3 +236,31 @@ def test_row_padded_frames(pf):
         assert a.feed(view, p) and b.feed(np.ascontiguousarray(view), p)
     a.sync(); b.sync()
     assert map_digest(a) == map_digest(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_general_coordinate_forms(force_float):
+    """The warp's general forms (IEEE division, saturating conversions, short clamps, looped border reflection) are
+    what every pixel takes for a degenerate homography or a frame wider than a short; a healthy frame only reaches
+    them through PF_FORCE_GENERAL, which is read once per process -- hence the child process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_package\n"
+        "from helpers import workloads, jitter_poses, compare_maps\n"
+        "import test_gpu_parity as T\n"
+        "pf = load_package(); from oracle import orc\n"
+        "wl = workloads(); cam = [640, 480, 500, 500, 320, 240]\n"
+        "poses = jitter_poses(4, seed=11); frames = [wl.noise_frame(480, 640, 30 + k) for k in range(4)]\n"
+        "for fused in (1, 0):\n"
+        "    g, o = T.run_pair(pf, orc, cam, poses, frames, n_prepare=2, force_float=%d, fused=fused)\n"
+        "    bad = compare_maps(g, o)\n"
+        "    assert bad == [], bad[:5]\n"
+        "print('general forms ok')\n"
+    ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), force_float)
+    env = dict(os.environ, PF_FORCE_GENERAL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "general forms ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
