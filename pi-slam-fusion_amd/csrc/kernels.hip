@@ -445,7 +445,7 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     } else {
         const int sx = sat_short(ux), sy = sat_short(uy);
         int sx0, sx1, sy0, sy1;
-        const bool near = reflect_is_near(sx, a.scols) && reflect_is_near(sx + 1, a.scols) &&
+        const bool near = a.plain && reflect_is_near(sx, a.scols) && reflect_is_near(sx + 1, a.scols) &&
                           reflect_is_near(sy, a.srows) && reflect_is_near(sy + 1, a.srows);
         if (__builtin_amdgcn_ballot_w64(!near) == 0) {        // canvas pixels next to the frame: one reflection
             sx0 = border_reflect_near(sx, a.scols); sx1 = border_reflect_near(sx + 1, a.scols);
