@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="Map2D.Scale (1 = cfg-A, 0.5 = shipped Default.cfg)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames kept in HBM")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--fused", type=int, default=None, help="pf_options.fused (default: the library's default)")
     ap.add_argument("--event-every", type=int, default=8,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
                          "(each event pair costs stream time; 0 = none, no roofline)")
@@ -131,8 +132,9 @@ def main():
     height = 100.0
     n_traj = K + W
     block = 128                                     # spatial-hash cell edge in tiles
+    extra = {} if args.fused is None else {"fused": args.fused}
     opt = pf.default_options(force_float=force_float, scale=args.scale, device=dev,
-                             shard_rank=rank, shard_count=N, shard_block=block)
+                             shard_rank=rank, shard_count=N, shard_block=block, **extra)
     m = pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt)
 
     # one sortie per rank; sortie j is flown inside a hash cell owned by rank j

@@ -280,11 +280,13 @@ bool FusionMap::prepare(const double plane7[7], const double cam[6], int n, cons
         for (int i = 0; i < n; i++) {
             if (!imgs[i].data) continue;
             const int cn = imgs[i].type == PF_8UC4 ? 4 : 3;
-            const int slot = acquire_slot((size_t)imgs[i].rows * imgs[i].cols * cn);
+            const size_t row_bytes = (size_t)imgs[i].cols * cn, step = imgs[i].step ? imgs[i].step : row_bytes;
+            if (step < row_bytes || step * (size_t)imgs[i].rows >= (1ull << 31)) { set_error("prepare: bad row step or frame of 2 GiB or more"); return false; }
+            const int slot = acquire_slot((size_t)imgs[i].rows * step);
             if (slot < 0 || !upload(&imgs[i], slot)) return false;
             std::lock_guard<std::mutex> q(qmu_);
             slots_[slot].queued = true;
-            queue_.push_back({ slot, nullptr, (long)imgs[i].cols * cn, imgs[i].rows, imgs[i].cols, cn, local[i] });
+            queue_.push_back({ slot, nullptr, (long)step, imgs[i].rows, imgs[i].cols, cn, local[i] });
         }
         qcv_.notify_all();
     }

@@ -36,7 +36,7 @@ def test_cfg1_plumbing(pf, orc, force_float, content, fused):
     cam, poses = wl.cfg1()
     gen = wl.noise_frame if content == "noise" else wl.smooth_frame
     frames = [gen(480, 640, k) for k in range(len(poses))]
-    g, o = run_pair(pf, orc, cam, poses, frames, force_float=force_float)
+    g, o = run_pair(pf, orc, cam, poses, frames, force_float=force_float, fused=fused)
     assert compare_maps(g, o) == []
 
 
