@@ -61,6 +61,33 @@ def cpu_baseline(wl, cam, poses, prep, frames_host, force_float, budget_s=15.0, 
             "sample": "first %d frames of the same 4000x3000 workload, 1 thread, %.1f s" % (n, dt)}
 
 
+def map2dcpu_rates(pf, wl, cam, poses, prep, frames_dev, frames_host, budget_s=8.0):
+    """The reference's other Map2D type on the same workload (BASELINE.json: "Map2DCPU/MultiBandMap2DCPU timed on
+    the host cores"): single-band Map2DCPU, the oracle restatement on 1 core and the HIP path on this GPU."""
+    sys.path.insert(0, ROOT)
+    from oracle import orc
+    o = orc.OracleMap(single_band=True)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, prep)
+    n, t0 = 0, time.perf_counter()
+    while n < 40 and time.perf_counter() - t0 < budget_s:
+        o.feed(frames_host[n % len(frames_host)], poses[n]); n += 1
+    dt = time.perf_counter() - t0
+    out = {"cpu": {"value": round(n / dt, 4), "unit": "keyframes/s", "cores": 1, "kind": "port",
+                   "sample": "first %d frames, Map2DCPU restatement, 1 thread, %.1f s" % (n, dt)}}
+    m = pf.Map2D.create(pf.TypeCPU, False)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, prep)
+    k = min(len(poses), 120)
+    for i in range(20):
+        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), cam[1], cam[0], poses[i])
+    m.sync()
+    t0 = time.perf_counter()
+    for i in range(20, k):
+        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), cam[1], cam[0], poses[i])
+    m.sync()
+    out["gpu"] = {"value": round((k - 20) / (time.perf_counter() - t0), 1), "unit": "keyframes/s", "frames": k - 20}
+    return out
+
+
 def cpu_baseline_allcores(force_float, budget_s=10.0):
     """BASELINE.md B2 ("generous"): the same oracle with its row / tile loops under OpenMP, all host
     cores, in a child process (the library flavour is chosen per process; the child never touches the GPU)."""
@@ -277,6 +304,10 @@ def main():
             allc = cpu_baseline_allcores(force_float)
             if allc:
                 out["cpu_baseline_allcores"] = allc
+            try:
+                out["map2dcpu_single_band"] = map2dcpu_rates(pf, wl, cam, sorties[0], prep, frames, hostf)
+            except Exception as e:                      # informational: never fail the headline line
+                out["map2dcpu_single_band"] = {"error": str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
