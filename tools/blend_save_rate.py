@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Output side of the path on the bench mosaic (dev tool): Ele::blend of every changed tile and save().
+usage: tools/blend_save_rate.py [--int16] [--frames N]"""
+import argparse, importlib, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import bench
+ap = argparse.ArgumentParser(); ap.add_argument("--int16", action="store_true"); ap.add_argument("--frames", type=int, default=120)
+a = ap.parse_args()
+import torch
+pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")
+cam = [4000, 3000, 3000, 3000, 2000, 1500]
+poses = wl.serpentine(cam, 100.0, a.frames)
+m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=0 if a.int16 else 1)
+assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+fr = [torch.randint(0, 256, (3000, 4000, 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+torch.cuda.synchronize()
+for k in range(a.frames):
+    m.feed_device(fr[k % 4].data_ptr(), 3000, 4000, poses[k])
+m.sync()
+nt = len(m.tiles())
+m.profile_reset(); m.profile_enable(1)
+t0 = time.perf_counter(); xy, out = m.blend_changed(cap=max(nt, 1)); t1 = time.perf_counter()
+print("blend_changed: %d of %d tiles in %.1f ms = %.0f tiles/s (%.1f Mpx/s of 256x256 BGR output, D2H included)" %
+      (len(xy), nt, (t1 - t0) * 1e3, len(xy) / (t1 - t0), len(xy) * 65536 / (t1 - t0) / 1e6))
+def dump():
+    for n, v in m.profile_read().items():
+        if v["launches"]:
+            print("    %-14s launches %5d  total %8.2f ms  alg %7.1f GB/s" % (n, v["launches"], v["ms"], v["alg_bytes"] / max(v["ms"], 1e-9) / 1e6))
+    m.profile_reset()
+dump()
+t0 = time.perf_counter(); img = m.save_to_memory(); t1 = time.perf_counter()
+print("save_to_memory: mosaic %dx%d (%d tiles) in %.1f ms" % (img[0].shape[1], img[0].shape[0], nt, (t1 - t0) * 1e3))
+dump()
