@@ -81,6 +81,13 @@ def test_rejections(pf, orc):
     assert g.feed(img, [0, 0, -100, s, 0, 0, c]) is False       # oblique view
     assert g.feed(img, poses[0]) is True
     assert g.stats()["rendered"] == 1
+    # a row step smaller than a row of pixels is refused at the boundary (cv::Mat could never say that)
+    import ctypes as C
+    bad = pf.Image(480, 640, pf.PF_8UC3, img.ctypes.data, 640 * 3 - 1)
+    pose = (C.c_double * 7)(*poses[1])
+    assert pf.lib().pf_feed(g._h, C.byref(bad), pose) == 0
+    assert b"row step" in pf.lib().pf_last_error()
+    assert g.stats()["rendered"] == 1
     assert pf.Map2D.create(pf.NoType) is None and pf.Map2D.create(pf.TypeRender) is None
 
 
