@@ -194,6 +194,13 @@ def main():
             oy = geo[1] + (cy + 0.5) * block * ele - 0.5 * (ys.max() + ys.min())
             sorties.append([[p[0] + ox, p[1] + oy] + p[2:] for p in base])
 
+    # size the tile store for the sortie up front (std::vector::reserve for HBM; `spreadMap` still grows the grid):
+    # hipMalloc and the driver's page clearing then happen here, not between two keyframes of the timed region
+    ele_m = m.grid()[1][4]
+    sx = [p[0] for p in sorties[rank]]; sy = [p[1] for p in sorties[rank]]
+    foot = 1.2 * max(cam[0], cam[1]) * height / cam[2]
+    m.reserve_tiles(int(((max(sx) - min(sx) + foot) / ele_m + 2) * ((max(sy) - min(sy) + foot) / ele_m + 2) * 1.1) + 64)
+
     # synthetic frames, resident in HBM before the timed region
     g = torch.Generator(device="cuda"); g.manual_seed(1234 + rank)
     frames = [torch.randint(0, 256, (3000, 4000, 3), dtype=torch.uint8, device="cuda", generator=g)

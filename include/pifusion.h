@@ -162,6 +162,10 @@ int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms
 int     pf_profile_reset(pf_map* m);
 /* frames rendered / rejected since creation */
 int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
+/* Allocator hint, no reference counterpart (MultiBandMap2DCPUEle's cv::Mat tiles, MultiBandMap2DCPU.h:32-51,
+ * come from the heap one by one): HBM for n_tiles more tiles is allocated and touched now instead of slab by
+ * slab while keyframes are being fused.  Call it after pf_prepare (which empties the store).                  */
+int     pf_reserve_tiles(pf_map* m, long long n_tiles);
 
 #ifdef __cplusplus
 }

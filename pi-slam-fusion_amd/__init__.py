@@ -94,6 +94,7 @@ def lib():
     L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
     L.pf_profile_reset.argtypes = [vp]
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
+    L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
     _lib = L
     return L
 
@@ -310,6 +311,10 @@ class Map2D:
         names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_longlong * cap)(); by = (C.c_double * cap)()
         k = lib().pf_profile_read(self._h, cap, names, ms, n, by)
         return {names[i].decode(): {"ms": ms[i], "launches": n[i], "alg_bytes": by[i]} for i in range(k)}
+
+    def reserve_tiles(self, n_tiles):
+        """Allocator hint: HBM for n_tiles more tiles now (see pf_reserve_tiles)."""
+        return bool(lib().pf_reserve_tiles(self._h, int(n_tiles)))
 
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

@@ -117,6 +117,7 @@ int pf_profile_enable(pf_map* m, int mode) { if (!m) return 0; m->impl.profile_e
 int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes)
 { return m ? m->impl.profile_read(cap, names, total_ms, launches, alg_bytes) : 0; }
 int pf_profile_reset(pf_map* m) { if (!m) return 0; m->impl.profile_reset(); return 1; }
+int pf_reserve_tiles(pf_map* m, long long n_tiles) { return m && m->impl.reserve_tiles(n_tiles) ? 1 : 0; }
 int pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped) { if (!m) return 0; m->impl.stats(rendered, rejected, dropped); return 1; }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 // the GPU, following the control flow of Map2DFusion/MultiBandMap2DCPU.cpp.
 #include "fusion_map.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,27 +41,45 @@ Tile* TileStore::find(int ix, int iy)
     return it == map_.end() ? nullptr : &it->second;
 }
 
+bool TileStore::add_chunk(size_t slots)
+{
+    void* p = nullptr;
+    if (hipMalloc(&p, slots * slot_bytes_) != hipSuccess) { set_error("tile store: hipMalloc failed"); return false; }
+    chunks_.push_back({ (char*)p, slots });
+    return true;
+}
+
 Tile* TileStore::get_or_create(int ix, int iy)
 {
     auto it = map_.find(key(ix, iy));
     if (it != map_.end()) return &it->second;
-    if (chunks_.empty() || next_in_chunk_ == chunk_slots_) {
+    if (chunks_.empty()) { if (!add_chunk(std::max<size_t>(16, (256u << 20) / slot_bytes_))) return nullptr; cur_ = 0; next_in_chunk_ = 0; }
+    if (next_in_chunk_ == chunks_[cur_].slots) {
         // slabs of ~256 MiB: few hipMallocs, tiles of one neighbourhood stay close in HBM
-        chunk_slots_ = std::max<size_t>(16, (256u << 20) / slot_bytes_);
-        void* p = nullptr;
-        if (hipMalloc(&p, chunk_slots_ * slot_bytes_) != hipSuccess) { set_error("tile store: hipMalloc failed"); return nullptr; }
-        chunks_.push_back((char*)p);
-        next_in_chunk_ = 0;
+        if (cur_ + 1 == chunks_.size() && !add_chunk(std::max<size_t>(16, (256u << 20) / slot_bytes_))) return nullptr;
+        cur_++; next_in_chunk_ = 0;
     }
     Tile t;
-    t.base = chunks_.back() + next_in_chunk_++ * slot_bytes_;
+    t.base = chunks_[cur_].p + next_in_chunk_++ * slot_bytes_;
     return &map_.emplace(key(ix, iy), t).first->second;
+}
+
+// pre-size the store (std::vector::reserve for HBM): one slab for what the slabs at hand cannot hold
+bool TileStore::reserve(size_t n_tiles, std::vector<std::pair<char*, size_t>>* fresh)
+{
+    size_t have = 0;
+    for (size_t i = cur_; i < chunks_.size(); i++) have += chunks_[i].slots - (i == cur_ ? next_in_chunk_ : 0);
+    if (have >= n_tiles) return true;
+    const size_t want = std::max<size_t>(n_tiles - have, 16);
+    if (!add_chunk(want)) return false;
+    if (fresh) fresh->push_back({ chunks_.back().p, want * slot_bytes_ });
+    return true;
 }
 
 void TileStore::clear()
 {
-    for (char* c : chunks_) (void)hipFree(c);
-    chunks_.clear(); map_.clear(); next_in_chunk_ = chunk_slots_ = 0;
+    for (auto& c : chunks_) (void)hipFree(c.p);
+    chunks_.clear(); map_.clear(); next_in_chunk_ = cur_ = 0;
 }
 
 bool DevBuf::reserve(size_t bytes)
@@ -204,6 +223,20 @@ void FusionMap::profile_reset()
     (void)sync_all();
     prof_harvest();
     for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; prof_tick_[i] = 0; }
+}
+
+// Allocator hint (no reference counterpart: the reference's tiles are cv::Mat on the heap): slabs for n more tiles
+// are allocated and touched now, so that a mosaic of known extent never meets hipMalloc -- or the driver's
+// page clearing behind it -- while keyframes are being fused.
+bool FusionMap::reserve_tiles(long long n_tiles)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || n_tiles <= 0 || !set_device()) return false;
+    std::vector<std::pair<char*, size_t>> fresh;
+    if (!store_.reserve((size_t)n_tiles, &fresh)) return false;
+    for (auto& f : fresh) HIP_OK(hipMemsetAsync(f.first, 0, f.second, stream_));
+    HIP_OK(hipStreamSynchronize(stream_));
+    return true;
 }
 
 void FusionMap::stats(long long* rendered, long long* rejected, long long* dropped)

@@ -35,14 +35,17 @@ public:
     void  configure(size_t slot_bytes) { slot_bytes_ = slot_bytes; }
     Tile* find(int ix, int iy);
     Tile* get_or_create(int ix, int iy);          // nullptr on HBM exhaustion
+    bool  reserve(size_t n_tiles, std::vector<std::pair<char*, size_t>>* fresh = nullptr);   // slabs for n more tiles now
     void  clear();
     size_t size() const { return map_.size(); }
     template <class F> void for_each(F f) { for (auto& kv : map_) f((int)(int32_t)(kv.first >> 32), (int)(int32_t)(kv.first & 0xffffffffu), kv.second); }
 private:
     static uint64_t key(int ix, int iy) { return ((uint64_t)(uint32_t)ix << 32) | (uint32_t)iy; }
     std::unordered_map<uint64_t, Tile> map_;
-    std::vector<char*> chunks_;
-    size_t slot_bytes_ = 0, chunk_slots_ = 0, next_in_chunk_ = 0;
+    struct Chunk { char* p; size_t slots; };
+    std::vector<Chunk> chunks_;                   // chunks_[cur_] is being filled, later ones are reserved ahead
+    size_t slot_bytes_ = 0, cur_ = 0, next_in_chunk_ = 0;
+    bool   add_chunk(size_t slots);
 };
 
 struct DevBuf {
@@ -100,6 +103,7 @@ public:
     int  profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes);
     void profile_reset();
     void stats(long long* rendered, long long* rejected, long long* dropped);
+    bool reserve_tiles(long long n_tiles);
     const pf_options& options() const { return opt_; }
 
 private:

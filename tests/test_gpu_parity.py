@@ -271,3 +271,23 @@ def test_general_coordinate_forms(force_float):
     env = dict(os.environ, PF_FORCE_GENERAL="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "general forms ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reserve_tiles_is_only_an_allocator_hint(pf):
+    """pf_reserve_tiles pre-sizes the tile store; tiles, their order of creation and their contents are unchanged."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(4, seed=21)
+    frames = [wl.noise_frame(480, 640, 90 + k) for k in range(4)]
+    maps = []
+    for reserve in (0, 3, 500):                              # none, fewer than needed (falls back to slabs), plenty
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+        if reserve:
+            assert m.reserve_tiles(reserve)
+        for f, p in zip(frames, poses):
+            assert m.feed(f, p)
+        assert m.sync()
+        maps.append(map_digest(m))
+    assert maps[0] == maps[1] == maps[2]
+    assert not pf.Map2D.create(pf.TypeMultiBandCPU, False).reserve_tiles(0)
