@@ -291,3 +291,29 @@ def test_reserve_tiles_is_only_an_allocator_hint(pf):
         maps.append(map_digest(m))
     assert maps[0] == maps[1] == maps[2]
     assert not pf.Map2D.create(pf.TypeMultiBandCPU, False).reserve_tiles(0)
+
+
+@pytest.mark.parametrize("thread", [False, True])
+def test_prepare_again_resets_the_map(pf, thread):
+    """prepare() may be called again at any time: frames in flight are finished or dropped, the
+    mosaic starts over -- the result equals a fresh map given the second preparation only."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    first = jitter_poses(5, seed=31)
+    second = jitter_poses(4, seed=32, step=(-15.0, 9.0))
+    frames = [wl.noise_frame(480, 640, 120 + k) for k in range(5)]
+    a = pf.Map2D.create(pf.TypeMultiBandCPU, thread)
+    assert a.prepare(wl.IDENTITY_PLANE, cam, first[:2])
+    for f, p in zip(frames, first):
+        assert a.feed(f, p)
+    assert a.prepare(wl.IDENTITY_PLANE, cam, second[:2])     # no sync in between: the pipeline is still full
+    for f, p in zip(frames, second):
+        assert a.feed(f, p)
+    assert a.sync()
+    b = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert b.prepare(wl.IDENTITY_PLANE, cam, second[:2])
+    for f, p in zip(frames, second):
+        assert b.feed(f, p)
+    assert b.sync()
+    assert a.grid() == b.grid()
+    assert map_digest(a) == map_digest(b)
