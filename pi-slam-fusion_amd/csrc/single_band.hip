@@ -3,6 +3,8 @@
 // (dis*254, floor 2), cv::warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) on 8UC4 through
 // OpenCV's 15-bit fixed-point bilinear taps, select `if (ele.a < dst.a) ele = dst`.
 #include "kernels.hpp"
+#include <cmath>
+#include <cstdlib>
 
 namespace pf {
 
@@ -56,6 +58,17 @@ void launch_weight32(hipStream_t s, float* w, int rows, int cols, int weight_typ
 
 __device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
+// (acc >> 15) saturated to 8 bits, four channels packed B | G<<8 | R<<16 | A<<24.  Each component is laundered through
+// an asm operand before the OR: left to itself the compiler turns the first two into `v_ashr_pk_u8_i32`, treats that
+// instruction's upper 16 result bits as zero, and on gfx950 they are not -- whatever the destination register held
+// before shows up in the red channel.
+__device__ __forceinline__ uint32_t pack_bgra(int accB, int accG, int accR, int accA)
+{
+    int b = sat_u8(accB >> 15), g = sat_u8(accG >> 15), r = sat_u8(accR >> 15), al = sat_u8(accA >> 15);
+    asm volatile("" : "+v"(b), "+v"(g), "+v"(r), "+v"(al));
+    return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | ((uint32_t)al << 24);
+}
+
 // one thread = one canvas pixel; a wave = one 64-pixel OpenCV coordinate block row
 __global__ __launch_bounds__(256) void k_single(const uint8_t* __restrict__ src, const uint8_t* __restrict__ w8, WarpArgs a,
                                                  const uint64_t* __restrict__ table, int tiles_x)
@@ -96,8 +109,7 @@ __global__ __launch_bounds__(256) void k_single(const uint8_t* __restrict__ src,
         tap(inx1 && iny0, sx + 1, sy, w[1]);
         tap(inx0 && iny1, sx, sy + 1, w[2]);
         tap(inx1 && iny1, sx + 1, sy + 1, w[3]);
-        out = (uint32_t)sat_u8(accB >> 15) | ((uint32_t)sat_u8(accG >> 15) << 8) |
-              ((uint32_t)sat_u8(accR >> 15) << 16) | ((uint32_t)sat_u8(accA >> 15) << 24);
+        out = pack_bgra(accB, accG, accR, accA);
     }
     uint32_t PF_GLOBAL* tile = (uint32_t PF_GLOBAL*)(ent & ~(uint64_t)1) + ((y & 255) * kElePixels + (x & 255));
     if (ent & 1) { *tile = (out >> 24) ? out : 0u; return; }   // fresh tile: zeros(...) then the select against alpha 0
@@ -105,10 +117,142 @@ __global__ __launch_bounds__(256) void k_single(const uint8_t* __restrict__ src,
     if ((cur >> 24) < (out >> 24)) *tile = out;                // Map2DCPU.cpp:326-327
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_single2: the same result with the techniques of the multi-band warp (kernels.hip, warp_fetch):
+//   * a thread keeps one canvas column and walks down 8 rows, two per step: the column terms of the fp64
+//     coordinate chain are formed once, the second pixel's coordinates and loads overlap the first one's loads;
+//   * correctly-rounded reciprocal without the scale/fixup steps and round-half-even by the 1.5*2^52 add when the
+//     whole wave is in the tame range (host-checked homography, `plain`), the general forms otherwise;
+//   * when the whole wave is strictly inside the frame: one unaligned 8-byte load per source row for both taps
+//     (BGR or BGRA) and one 2-byte load per row of the weight-byte plane, instead of 16 byte loads;
+//   * one tile-table entry per thread (8 rows never straddle a tile).
+struct SingleTaps { uint32_t lo0, hi0, lo1, hi1, wa; int X, Y; bool fast; };
+
+__device__ __forceinline__ double rcp_mid(double d)              // see kernels.hip rcp_mid_range
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
+}
+
+struct SingleCol { double m0xb, m3xb, m6xb, m0x1, m3x1, m6x1; };
+
+__device__ __forceinline__ void single_coords(const WarpArgs& a, const SingleCol& col, int y, int plain, int& X, int& Y)
+{
+    const double X0 = col.m0xb + a.M[1] * y + a.M[2];
+    const double Y0 = col.m3xb + a.M[4] * y + a.M[5];
+    const double W0 = col.m6xb + a.M[7] * y + a.M[8];
+    const double W  = W0 + col.m6x1;
+    const double xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
+    const double Wn = rcp_mid(W);
+    const double px = xn * Wn * 32., py = yn * Wn * 32.;        // (1/W)*32 == 32/W bit for bit; scaling by 32 commutes with rounding
+    const bool tame = fabs(px) < 1.0e9 && fabs(py) < 1.0e9;
+    if (plain && __builtin_amdgcn_ballot_w64(!tame) == 0) {
+        constexpr double kMagic = 6755399441055744.0;
+        X = (int)(uint32_t)(unsigned long long)__double_as_longlong(px + kMagic);
+        Y = (int)(uint32_t)(unsigned long long)__double_as_longlong(py + kMagic);
+    } else {
+        const double Wl = (W ? 1. / W : 0) * 32.;
+        X = __double2int_rn(xn * Wl);                            // cvt saturates == clamp + cvRound
+        Y = __double2int_rn(yn * Wl);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_single2(const uint8_t* __restrict__ src, const uint8_t* __restrict__ w8, WarpArgs a,
+                                                  const uint64_t* __restrict__ table, int tiles_x, int plain)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xb = a.x_off + blockIdx.x * 64;
+    const int x  = xb + lane;
+    const int yb = a.y_off + blockIdx.y * 32 + wave * 8;
+    const uint64_t ent = table[(yb >> 8) * tiles_x + (x >> 8)];
+    if (!ent) return;
+    const SingleCol col = { a.M[0] * xb, a.M[3] * xb, a.M[6] * xb, a.M[0] * lane, a.M[3] * lane, a.M[6] * lane };
+    const int cn = a.src_cn, step = (int)a.sstep;
+    const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;
+    auto ss = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+    typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+    typedef unsigned short us1 __attribute__((aligned(1)));
+
+    auto fetch = [&](int y) {
+        SingleTaps t;
+        single_coords(a, col, y, plain, t.X, t.Y);
+        const int ux = t.X >> 5, uy = t.Y >> 5;
+        const bool in = (unsigned)ux < (unsigned)(a.scols - 1) && (unsigned)uy < (unsigned)(a.srows - 2);
+        t.fast = plain && __builtin_amdgcn_ballot_w64(!in) == 0;
+        t.lo0 = t.hi0 = t.lo1 = t.hi1 = t.wa = 0;
+        if (t.fast) {
+            const uint32_t off = (uint32_t)(__mul24(uy, step) + __mul24(cn, ux)), woff = (uint32_t)(__mul24(uy, a.scols) + ux);
+            const u2 b0 = *(const u2*)(src + off), b1 = *(const u2*)(src + off + (uint32_t)step);
+            const uint32_t w0 = *(const us1*)(w8 + woff), w1 = *(const us1*)(w8 + woff + (uint32_t)a.scols);
+            t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y; t.wa = w0 | (w1 << 16);
+        }
+        return t;
+    };
+    auto finish = [&](const SingleTaps& t, int y) {
+        const int X = t.X, Y = t.Y;
+        // integer taps: saturate_cast<short>(w*32768); the products are exact on the 1/32 grid and sum to
+        // 32768 except at (0,0) (32768 -> 32767, the missing 1 goes to another tap: no effect on outputs)
+        const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+        int w[4] = { __float2int_rn((1.f - fy) * (1.f - fx) * 32768.f), __float2int_rn((1.f - fy) * fx * 32768.f),
+                     __float2int_rn(fy * (1.f - fx) * 32768.f), __float2int_rn(fy * fx * 32768.f) };
+        if (w[0] > 32767) w[0] = 32767;
+        w[3] += 32768 - (w[0] + w[1] + w[2] + w[3]);
+        uint32_t out = 0;
+        if (t.fast) {
+            const uint32_t p00 = t.lo0, p01 = __builtin_amdgcn_perm(t.hi0, t.lo0, hisel);
+            const uint32_t p10 = t.lo1, p11 = __builtin_amdgcn_perm(t.hi1, t.lo1, hisel);
+            auto byte = [](uint32_t v, int k) { return (int)((v >> (8 * k)) & 0xffu); };
+            const int accB = (1 << 14) + __mul24(byte(p00, 0), w[0]) + __mul24(byte(p01, 0), w[1]) + __mul24(byte(p10, 0), w[2]) + __mul24(byte(p11, 0), w[3]);
+            const int accG = (1 << 14) + __mul24(byte(p00, 1), w[0]) + __mul24(byte(p01, 1), w[1]) + __mul24(byte(p10, 1), w[2]) + __mul24(byte(p11, 1), w[3]);
+            const int accR = (1 << 14) + __mul24(byte(p00, 2), w[0]) + __mul24(byte(p01, 2), w[1]) + __mul24(byte(p10, 2), w[2]) + __mul24(byte(p11, 2), w[3]);
+            const int accA = (1 << 14) + __mul24(byte(t.wa, 0), w[0]) + __mul24(byte(t.wa, 1), w[1]) + __mul24(byte(t.wa, 2), w[2]) + __mul24(byte(t.wa, 3), w[3]);
+            out = pack_bgra(accB, accG, accR, accA);
+        } else {
+            const int sx = ss(X >> 5), sy = ss(Y >> 5);
+            if (!(sx >= a.scols || sx + 1 < 0 || sy >= a.srows || sy + 1 < 0)) {
+                const bool inx0 = sx >= 0, inx1 = sx + 1 < a.scols, iny0 = sy >= 0, iny1 = sy + 1 < a.srows;
+                int accB = 1 << 14, accG = 1 << 14, accR = 1 << 14, accA = 1 << 14;
+                auto tap = [&](bool in, int tx, int ty, int wt) {
+                    if (!in) return;                                   // BORDER_CONSTANT: the tap contributes cval = 0
+                    const int off = __mul24(ty, step) + tx * cn;
+                    const int b = src[off], g = src[off + 1], r = src[off + 2], al = w8[__mul24(ty, a.scols) + tx];
+                    accB += __mul24(b, wt); accG += __mul24(g, wt); accR += __mul24(r, wt); accA += __mul24(al, wt);
+                };
+                tap(inx0 && iny0, sx, sy, w[0]);
+                tap(inx1 && iny0, sx + 1, sy, w[1]);
+                tap(inx0 && iny1, sx, sy + 1, w[2]);
+                tap(inx1 && iny1, sx + 1, sy + 1, w[3]);
+                out = pack_bgra(accB, accG, accR, accA);
+            }
+        }
+        uint32_t PF_GLOBAL* tile = (uint32_t PF_GLOBAL*)(ent & ~(uint64_t)1) + ((y & 255) * kElePixels + (x & 255));
+        if (ent & 1) { *tile = (out >> 24) ? out : 0u; return; }   // fresh tile: zeros(...) then the select against alpha 0
+        const uint32_t cur = *tile;
+        if ((cur >> 24) < (out >> 24)) *tile = out;                // Map2DCPU.cpp:326-327
+    };
+#pragma unroll 1
+    for (int k = 0; k < 8; k += 2) {
+        const SingleTaps ta = fetch(yb + k), tb = fetch(yb + k + 1);
+        finish(ta, yb + k); finish(tb, yb + k + 1);
+    }
+}
+
 void launch_single(hipStream_t s, const uint8_t* src, const uint8_t* w8, const WarpArgs& a, const uint64_t* table, int tiles_x)
 {
-    dim3 grid(a.wcols / 64, a.wrows / 4), block(256);
-    hipLaunchKernelGGL(k_single, grid, block, 0, s, src, w8, a, table, tiles_x);
+    static const bool old_kernel = getenv("PF_SINGLE_OLD") != nullptr;     // diagnostics: the one-pixel-per-thread form
+    if (old_kernel) {
+        dim3 grid(a.wcols / 64, a.wrows / 4), block(256);
+        hipLaunchKernelGGL(k_single, grid, block, 0, s, src, w8, a, table, tiles_x);
+        return;
+    }
+    // plain: see FusedWarp::plain (kernels.hip)
+    int plain = a.srows <= 32767 && a.scols <= 32767 && !getenv("PF_FORCE_GENERAL");
+    for (int i = 0; i < 9; i++) if (!(std::fabs(a.M[i]) < 0x1p400)) plain = 0;
+    dim3 grid(a.wcols / 64, a.wrows / 32), block(256);
+    hipLaunchKernelGGL(k_single2, grid, block, 0, s, src, w8, a, table, tiles_x, plain);
 }
 
 }  // namespace pf

@@ -102,3 +102,28 @@ def test_single_band_shards(pf):
     assert sorted(got) == sorted(ref.tiles()) and len(a.tiles()) and len(b.tiles())
     for t in ref.tiles():
         assert np.array_equal(got[t], ref.tile_bgra(*t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", ["PF_SINGLE_OLD", "PF_FORCE_GENERAL"])
+def test_single_band_other_kernel_forms(env):
+    """The one-pixel-per-thread kernel and the general coordinate/tap forms of k_single2 give the same tiles; both
+    are selected by environment switches that are read once per process, hence the child process."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from conftest import load_package\n"
+        "from helpers import workloads, jitter_poses\n"
+        "import test_single_band as T\n"
+        "pf = load_package(); from oracle import orc\n"
+        "wl = workloads(); cam = [640, 480, 500, 500, 320, 240]\n"
+        "poses = jitter_poses(5, seed=23); frames = [wl.noise_frame(480, 640, 60 + k) for k in range(5)]\n"
+        "g, o = T.run_pair(pf, orc, cam, poses, frames, pf.TypeCPU, n_prepare=2)\n"
+        "for t in o.tiles():\n"
+        "    assert np.array_equal(g.tile_bgra(*t), o.tile_bgra(*t)), t\n"
+        "print('single band ok')\n"
+    ) % (here, os.path.dirname(here))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "single band ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
