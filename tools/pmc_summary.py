@@ -20,7 +20,8 @@ from collections import defaultdict
 
 SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_pyrdown", "pyrdown_img"),
          ("k_lap_select", "lap_select"), ("k_level", "level"), ("k_blend_gather", "blend_gather"), ("k_collapse", "collapse"),
-         ("k_blend_finish", "blend_finish"), ("k_mosaic_gather", "mosaic_gather"), ("k_save_finish", "save_finish")]
+         ("k_blend_finish", "blend_finish"), ("k_mosaic_gather", "mosaic_gather"), ("k_save_finish", "save_finish"),
+         ("k_single", "single_band")]
 
 
 def short(name):

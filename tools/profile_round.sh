@@ -24,3 +24,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD
     rocprofv3 --pmc $set --output-format csv -d $out/prof_${tag}_f32_sq$i -o q -- $B > $out/prof_${tag}_f32_sq$i.log 2>&1 || echo "set $i failed"
     echo "sq set $i done"
 done
+# Map2DCPU (single band) path
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_${tag}_sb_stats -o s -- python3 tools/single_band_rate.py > $out/prof_${tag}_sb_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/prof_${tag}_sb_fetch -o f -- python3 tools/single_band_rate.py > $out/prof_${tag}_sb_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/prof_${tag}_sb_write -o w -- python3 tools/single_band_rate.py > $out/prof_${tag}_sb_write.log 2>&1
+echo "single band done"
