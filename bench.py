@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames kept in HBM")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--fused", type=int, default=None, help="pf_options.fused (default: the library's default)")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=16,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
                          "(each event pair costs stream time; 0 = none, no roofline)")
     args = ap.parse_args()

@@ -121,6 +121,8 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return; }
     for (int i = 0; i < kTableRing; i++)
         if (hipEventCreateWithFlags(&table_ev_[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return; }
+    for (int i = 0; i < kMarks; i++)
+        if (hipEventCreateWithFlags(&mark_ev_[i], hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return; }
     init_ok_ = true;
     if (thread_) worker_ = std::thread([this] { worker(); });
 }
@@ -141,7 +143,7 @@ FusionMap::~FusionMap()
         bool shared = lvl_stream_[i] == stream_;
         for (int k = 1; k < i; k++) shared = shared || lvl_stream_[k] == lvl_stream_[i];
         if (i > 0 && lvl_stream_[i] && !shared) (void)hipStreamDestroy(lvl_stream_[i]);
-        for (int k = 0; k < kTableRing; k++) if (lvl_ev_[i][k]) (void)hipEventDestroy(lvl_ev_[i][k]);
+        for (int k = 0; k < kLvlRing; k++) if (lvl_ev_[i][k]) (void)hipEventDestroy(lvl_ev_[i][k]);
         gw_[i].release(); gw2_[i].release();
     }
     for (auto& s : slots_) { if (s.dev) (void)hipFree(s.dev); if (s.consumed) (void)hipEventDestroy(s.consumed); }
@@ -149,6 +151,7 @@ FusionMap::~FusionMap()
         if (table_host_[i]) (void)hipHostFree(table_host_[i]);
         table_dev_[i].release();
         if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
+        if (i < kMarks && mark_ev_[i]) (void)hipEventDestroy(mark_ev_[i]);
     }
     for (int i = 0; i < kMaxLevels; i++) { g_[i].release(); wgt_[i].release(); blend_lv_[i].release(); }
     blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release(); wmap_.release();
@@ -164,6 +167,7 @@ hipError_t FusionMap::sync_all()
 {
     if (!flush_pipeline()) return hipErrorUnknown;
     hipError_t e = hipStreamSynchronize(stream_);
+    if (e == hipSuccess) synced_no_ = work_no_;
     for (int i = 1; i < kMaxLevels; i++)
         if (lvl_stream_[i] && lvl_stream_[i] != stream_) { hipError_t e2 = hipStreamSynchronize(lvl_stream_[i]); if (e == hipSuccess) e = e2; }
     return e;
@@ -591,6 +595,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // tile table (Apply's tile loop, .cpp:478-492): slot address | fresh bit
     const int ring = (int)(frame_seq_++ % kTableRing);
     if (table_pending_[ring]) { HIP_OK(hipEventSynchronize(table_ev_[ring])); table_pending_[ring] = false; }
+    if (!wait_for(table_release_[ring])) return false;
     uint64_t* tab = table_host_[ring];
     std::vector<Tile*> touched;
     for (int y = 0; y < ty; y++)
@@ -671,7 +676,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         // frame f-1 (tiles are updated in feed order).  GW buffers are double-buffered by frame parity; a writer
         // waits for the reader two frames back.
         const unsigned long long fidx = frame_seq_ - 1;
-        const int slot = (int)(fidx % kTableRing);
+        const int slot = (int)(fidx % kLvlRing);
         DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
         for (int i = 0; i < L; i++) {
             if (!lvl_stream_[i]) {
@@ -684,7 +689,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 else if (i > n_upper) lvl_stream_[i] = lvl_stream_[1 + (i - 1) % n_upper];
                 else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
             }
-            for (int k = 0; k < kTableRing; k++)
+            for (int k = 0; k < kLvlRing; k++)
                 if (!lvl_ev_[i][k]) HIP_OK(hipEventCreateWithFlags(&lvl_ev_[i][k], hipEventDisableTiming));
         }
         for (int i = 0; i < L; i++) {
@@ -692,7 +697,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
             const bool top = (i + 1 == L);
             if (i > 0) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i - 1][slot], 0));
-            if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kTableRing)], 0));
+            if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kLvlRing)], 0));
             // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
             double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
             if (i == 0) bytes += (double)a.src_cn * f.rows * f.cols;
@@ -733,10 +738,44 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     }
     }
     HIP_OK(hipGetLastError());
-    if (!table_pending_[ring] && !(fused && opt_.fused == 1)) { HIP_OK(hipEventRecord(table_ev_[ring], stream_)); table_pending_[ring] = true; }   // last reader of the table
+    if (!table_pending_[ring] && !(fused && opt_.fused == 1)) {
+        // this frame's kernels were the last readers of its tile table (fused = 1 retires it in launch_pipeline)
+        if (!submitted()) return false;
+        table_release_[ring] = work_no_;
+    }
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
     for (Tile* t : touched) { t->fresh = false; t->changed = true; }
     n_rendered_++;
+    return true;
+}
+
+// Retirement without an event per frame (see the header): count the submission, drop a marker now and then.
+bool FusionMap::submitted()
+{
+    work_no_++;
+    if (work_no_ % kMarkEvery == 0) {
+        HIP_OK(hipEventRecord(mark_ev_[mark_next_], stream_));
+        mark_no_[mark_next_] = work_no_;
+        mark_next_ = (mark_next_ + 1) % kMarks;
+    }
+    return true;
+}
+
+// block until submission `no` on stream_ has completed
+bool FusionMap::wait_for(unsigned long long no)
+{
+    if (no <= synced_no_) return true;
+    int best = -1;
+    for (int i = 0; i < kMarks; i++)
+        if (mark_no_[i] >= no && (best < 0 || mark_no_[i] < mark_no_[best])) best = i;
+    if (best < 0) {                                             // nothing recorded past it yet: mark now
+        HIP_OK(hipEventRecord(mark_ev_[mark_next_], stream_));
+        mark_no_[mark_next_] = work_no_;
+        best = mark_next_;
+        mark_next_ = (mark_next_ + 1) % kMarks;
+    }
+    HIP_OK(hipEventSynchronize(mark_ev_[best]));
+    synced_no_ = std::max(synced_no_, mark_no_[best]);
     return true;
 }
 
@@ -773,7 +812,8 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
     }
     // the frame whose last level just ran (this frame itself when L == 1) no longer needs its tile table
     const PipeFrame* done = L >= 2 ? (pipe_[L - 1].valid ? &pipe_[L - 1] : nullptr) : cur;
-    if (done) { HIP_OK(hipEventRecord(table_ev_[done->ring], stream_)); table_pending_[done->ring] = true; }
+    if (!submitted()) return false;
+    if (done) table_release_[done->ring] = work_no_;
     for (int s = L - 1; s >= 2; s--) pipe_[s] = pipe_[s - 1];
     if (L >= 2) { if (cur) pipe_[1] = *cur; else pipe_[1].valid = false; }
     launch_seq_++;

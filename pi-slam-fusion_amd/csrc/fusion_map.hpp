@@ -142,15 +142,28 @@ private:
     // per-frame workspace (grow-only)
     DevBuf g_[kMaxLevels], wgt_[kMaxLevels], gw_[kMaxLevels], gw2_[kMaxLevels];
     hipStream_t lvl_stream_[kMaxLevels]{};          // fused pipeline: one stream per level ([0] aliases stream_)
-    static constexpr int kTableRing = 16;           // > pipeline depth (kMaxLevels)
-    hipEvent_t  lvl_ev_[kMaxLevels][kTableRing]{};  // level i of the frame in ring slot k has run
+    static constexpr int kTableRing = 64;           // tile tables in flight (see retire())
+    static constexpr int kLvlRing = 16;
+    hipEvent_t  lvl_ev_[kMaxLevels][kLvlRing]{};    // fused = 2/3: level i of the frame in ring slot k has run
     hipStream_t prof_stream_ = nullptr;
     static constexpr int kUpperStreams = 1;         // streams shared by pyramid levels >= 1
     uint64_t*  table_host_[kTableRing]{};
     DevBuf     table_dev_[kTableRing];
     size_t     table_cap_ = 0;
-    hipEvent_t table_ev_[kTableRing]{};             // last reader of the ring slot done
+    hipEvent_t table_ev_[kTableRing]{};             // fused = 2/3: last reader of the ring slot done (own stream)
     bool       table_pending_[kTableRing]{};
+    // Everything else retires on stream_, and an event record between two dependent launches costs ~18 us of
+    // stream time on this stack: instead of one event per frame, a ring slot remembers the number of the launch that
+    // reads it last (work_no_ counts submissions on stream_), a marker event is recorded every kMarkEvery
+    // submissions, and a slot is reused after waiting for a marker at or past its number.
+    static constexpr int kMarkEvery = 32, kMarks = 4;           // kTableRing - kMaxLevels >= kMarkEvery
+    unsigned long long work_no_ = 0, synced_no_ = 0;
+    unsigned long long table_release_[kTableRing]{};
+    hipEvent_t mark_ev_[kMarks]{};
+    unsigned long long mark_no_[kMarks]{};
+    int  mark_next_ = 0;
+    bool submitted();                                           // call once per submission on stream_
+    bool wait_for(unsigned long long no);
     unsigned long long frame_seq_ = 0;
 
     // pipelined level launches (opt_.fused == 1): pipe_[s] is the frame whose level s runs in the next launch
