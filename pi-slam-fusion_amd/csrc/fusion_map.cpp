@@ -2,7 +2,6 @@
 // the GPU, following the control flow of Map2DFusion/MultiBandMap2DCPU.cpp.
 #include "fusion_map.hpp"
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
