@@ -8,19 +8,28 @@ cfg-A: Map2D.Scale=1, 5 bands): serpentine sortie, 80 %/60 % overlap, yaw +-5 de
 roll/pitch +-2 deg.
 
 Launch: `python bench.py --gpus N --steps K --warmup W`, or under torchrun with one rank
-per GPU.  With N>1 the mosaic tiles are sharded by spatial hash (no data-path collective
-in feed); N concurrent sorties are fed interleaved and every rank renders the
-frames that land on tiles it owns -> weak scaling; value = all frames / max-over-ranks time.
+per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
+  --shard weak   (default) N concurrent sorties, each inside a hash cell owned by another rank:
+                 no frame lands on two ranks -> N replicas, "scaling": "weak".
+  --shard strong ONE sortie whose tiles are split over the ranks (hash cell = --shard-block tiles):
+                 every rank renders every frame that touches a tile it owns, with halo recompute;
+                 K is the sortie's frame count whatever N is -> "scaling": "strong"; the line also
+                 carries the per-rank halo-recompute factor and the timed seam exchange (blend of
+                 all tiles with neighbour strips from other ranks, gather + save on rank 0).
 
 Rank 0 prints ONE JSON line (contract in the task statement), including
   roofline     : dominant kernel, algorithmic bytes / HIP-event time on the map's stream
   cpu_baseline : the oracle (CPU port of MultiBandMap2DCPU) timed on a bounded sample.
+Every leg after the timed GPU region is guarded: a failure there becomes {"error": ...} inside
+the line and never loses the GPU measurement.
 """
 import argparse
+import hashlib
 import importlib
 import importlib.util
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +37,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SIMDS = 256 * 4                # CUs x SIMDs
+MAX_CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md chip table
+CAM = [4000, 3000, 3000, 3000, 2000, 1500]
+HEIGHT = 100.0
 
 
 def load_package():
@@ -42,17 +55,72 @@ def load_package():
     return mod
 
 
-def cpu_baseline(wl, cam, poses, prep, frames_host, force_float, budget_s=15.0, max_frames=40):
+# ----------------------------------------------------------------- helpers (CPU-testable)
+def pose_at(poses, n):
+    """The n-th pose of a leg that may run longer than the sortie: the sortie is flown again."""
+    return poses[n % len(poses)]
+
+
+def event_every_for(steps, requested=None):
+    """HIP events around every n-th launch: about 8 timed launches whatever --steps is."""
+    if requested is not None:
+        return max(0, requested)
+    return max(1, steps // 8)
+
+
+def guarded(fn, *a, **kw):
+    """Run a reporting leg; a failure becomes a record instead of an exception."""
+    try:
+        return fn(*a, **kw)
+    except BaseException as e:            # noqa: BLE001 -- incl. SystemExit/KeyboardInterrupt from a child
+        if isinstance(e, KeyboardInterrupt):
+            raise
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def kernels_sha():
+    """Build id of the device code the PMC numbers under profiles/ belong to."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "pi-slam-fusion_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(dtype_key, kernel):
+    """HBM traffic / VALU instructions per launch from the committed PMC passes (profiles/pmc_traffic.json),
+    with the build they were taken at; `current` says whether that is the device code being run."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    rec = tj.get(dtype_key, {}).get(kernel)
+    if rec is None:
+        return None
+    if not isinstance(rec, dict):
+        rec = {"traffic": rec}
+    meta = tj.get("_meta", {})
+    out = dict(rec)
+    out["git_sha"] = meta.get("git_sha")
+    out["kernels_sha"] = meta.get("kernels_sha")
+    out["current"] = meta.get("kernels_sha") == kernels_sha()
+    return out
+
+
+# ----------------------------------------------------------------------------- CPU legs
+def cpu_baseline(wl, poses, prep, frames_host, force_float, budget_s=15.0, max_frames=40):
     """The oracle (kind 'port': this repo's C restatement of MultiBandMap2DCPU, 1 thread,
     like the reference's single render thread on a stock OpenCV 2.4.9) on the first frames
     of the same workload."""
     sys.path.insert(0, ROOT)
     from oracle import orc
     o = orc.OracleMap(force_float=force_float)
-    assert o.prepare(wl.IDENTITY_PLANE, cam, prep)
+    assert o.prepare(wl.IDENTITY_PLANE, CAM, prep)
     n, t0 = 0, time.perf_counter()
     while n < max_frames:
-        o.feed(frames_host[n % len(frames_host)], poses[n])
+        o.feed(frames_host[n % len(frames_host)], pose_at(poses, n))
         n += 1
         if time.perf_counter() - t0 > budget_s:
             break
@@ -61,37 +129,37 @@ def cpu_baseline(wl, cam, poses, prep, frames_host, force_float, budget_s=15.0, 
             "sample": "first %d frames of the same 4000x3000 workload, 1 thread, %.1f s" % (n, dt)}
 
 
-def map2dcpu_rates(pf, wl, cam, poses, prep, frames_dev, frames_host, budget_s=8.0):
+def map2dcpu_rates(pf, wl, poses, prep, frames_dev, frames_host, budget_s=8.0):
     """The reference's other Map2D type on the same workload (BASELINE.json: "Map2DCPU/MultiBandMap2DCPU timed on
     the host cores"): single-band Map2DCPU, the oracle restatement on 1 core and the HIP path on this GPU."""
     sys.path.insert(0, ROOT)
     from oracle import orc
     o = orc.OracleMap(single_band=True)
-    assert o.prepare(wl.IDENTITY_PLANE, cam, prep)
+    assert o.prepare(wl.IDENTITY_PLANE, CAM, prep)
     n, t0 = 0, time.perf_counter()
     while n < 40 and time.perf_counter() - t0 < budget_s:
-        o.feed(frames_host[n % len(frames_host)], poses[n]); n += 1
+        o.feed(frames_host[n % len(frames_host)], pose_at(poses, n)); n += 1
     dt = time.perf_counter() - t0
     out = {"cpu": {"value": round(n / dt, 4), "unit": "keyframes/s", "cores": 1, "kind": "port",
                    "sample": "first %d frames, Map2DCPU restatement, 1 thread, %.1f s" % (n, dt)}}
     m = pf.Map2D.create(pf.TypeCPU, False)
-    assert m.prepare(wl.IDENTITY_PLANE, cam, prep)
-    k = min(len(poses), 120)
-    for i in range(20):
-        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), cam[1], cam[0], poses[i])
+    assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
+    warm, timed = 20, 100
+    for i in range(warm):
+        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), CAM[1], CAM[0], pose_at(poses, i))
     m.sync()
     t0 = time.perf_counter()
-    for i in range(20, k):
-        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), cam[1], cam[0], poses[i])
+    for i in range(warm, warm + timed):
+        m.feed_device(frames_dev[i % len(frames_dev)].data_ptr(), CAM[1], CAM[0], pose_at(poses, i))
     m.sync()
-    out["gpu"] = {"value": round((k - 20) / (time.perf_counter() - t0), 1), "unit": "keyframes/s", "frames": k - 20}
+    out["gpu"] = {"value": round(timed / (time.perf_counter() - t0), 1), "unit": "keyframes/s", "frames": timed}
+    m.close()
     return out
 
 
 def cpu_baseline_allcores(force_float, budget_s=10.0):
     """BASELINE.md B2 ("generous"): the same oracle with its row / tile loops under OpenMP, all host
     cores, in a child process (the library flavour is chosen per process; the child never touches the GPU)."""
-    import subprocess
     code = (
         "import sys, time, json, os; sys.path.insert(0, %r)\n"
         "nth = min(16, len(os.sched_getaffinity(0)))        # a 1-GPU box gives this job a 16-CPU share\n"
@@ -110,11 +178,78 @@ def cpu_baseline_allcores(force_float, budget_s=10.0):
         "print(json.dumps({'value': round(n / dt, 4), 'unit': 'keyframes/s', 'cores': nth, 'kind': 'port',\n"
         "                  'sample': 'first %%d frames, OpenMP over rows/tiles, %%.1f s' %% (n, dt)}))\n"
     ) % (ROOT, force_float, budget_s)
-    try:
-        out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
-        return json.loads(out.stdout.decode().strip().splitlines()[-1])
-    except Exception:
-        return None
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    lines = out.stdout.decode().strip().splitlines()
+    if not lines:
+        raise RuntimeError("child printed nothing: " + out.stderr.decode()[-200:])
+    return json.loads(lines[-1])
+
+
+def host_feed_rate(pf, wl, poses, prep, frames_host, force_float, frames=60):
+    """PCIe-inclusive rate (SURVEY 3.1 puts the H2D copy inside feed): pageable host frames through pf_feed.
+    Reported next to `value`, never as `value`."""
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float)
+    assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
+    for k in range(6):
+        assert m.feed(frames_host[k % len(frames_host)], pose_at(poses, k))
+    m.sync()
+    t0 = time.perf_counter()
+    for k in range(6, 6 + frames):
+        assert m.feed(frames_host[k % len(frames_host)], pose_at(poses, k))
+    m.sync()
+    dt = time.perf_counter() - t0
+    m.close()
+    nbytes = CAM[0] * CAM[1] * 3
+    return {"value": round(frames / dt, 1), "unit": "keyframes/s", "frames": frames,
+            "h2d_GBps": round(nbytes * frames / dt / 1e9, 1),
+            "note": "pageable host frames through pf_feed (36 MB H2D per keyframe inside feed)"}
+
+
+# ------------------------------------------------------------------------------ GPU legs
+def timed_run(m, run, W, K, event_every, barrier):
+    """W untimed steps with every kernel timed (finds the dominant kernel), then K timed steps with HIP events
+    around every n-th launch of that kernel only.  Returns (seconds, dominant kernel, its record, warm-up records)."""
+    m.profile_enable(1)
+    run(0, W)
+    m.sync()
+    prof = m.profile_read()
+    names = list(prof.keys())
+    dom = max(names, key=lambda n: prof[n]["ms"]) if W > 0 and any(prof[n]["launches"] for n in names) else "level0_fused"
+    m.profile_reset()
+    m.profile_enable(((2 + names.index(dom)) | (event_every << 8)) if event_every else 0)
+    import torch
+    barrier()
+    t0 = time.perf_counter()
+    run(W, W + K)
+    m.sync()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    p = m.profile_read()[dom]
+    m.profile_enable(0)
+    return t1 - t0, dom, p, prof
+
+
+def roofline_record(dom, p, dtype_key, event_every):
+    ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+    launches = max(p["launches"], 1)
+    us = p["ms"] / launches * 1e3
+    pmc = pmc_record(dtype_key, dom)
+    rec = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4),
+           "traffic": pmc.get("traffic") if pmc else None,
+           "avg_launch_us": round(us, 2), "alg_bytes_per_launch": round(p["alg_bytes"] / launches),
+           "launches": p["launches"], "timed_every": event_every}
+    if pmc:
+        rec["pmc_build"] = {"git_sha": pmc.get("git_sha"), "kernels_sha": pmc.get("kernels_sha"), "current": pmc.get("current")}
+        if pmc.get("valu_insts") and us > 0:
+            # a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (MI355X_MICROARCH.md, cycle table)
+            frac = pmc["valu_insts"] * 4.0 / (SIMDS * us * 1e-6 * MAX_CLOCK_GHZ * 1e9)
+            rec["valu"] = {"insts_per_launch": pmc["valu_insts"], "issue_frac": round(frac, 4),
+                           "note": "VALU wave-instructions x 4 cycles / (1024 SIMDs x launch time x 2.4 GHz max clock); "
+                                   "the launch is VALU-issue limited, not HBM limited, when this exceeds `frac`"}
+            rec["limiter"] = "valu-issue" if frac > rec["frac"] else "hbm"
+    return rec
 
 
 def main():
@@ -122,14 +257,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--int16", action="store_true", help="reference default pyramids (CV_16SC3) instead of ForceFloat")
+    ap.add_argument("--int16", action="store_true", help="headline on the reference-default pyramids (CV_16SC3) instead of ForceFloat")
     ap.add_argument("--scale", type=float, default=1.0, help="Map2D.Scale (1 = cfg-A, 0.5 = shipped Default.cfg)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames kept in HBM")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU / host-feed / second-dtype legs (profiling runs)")
     ap.add_argument("--fused", type=int, default=None, help="pf_options.fused (default: the library's default)")
-    ap.add_argument("--event-every", type=int, default=16,
+    ap.add_argument("--event-every", type=int, default=None,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
-                         "(each event pair costs stream time; 0 = none, no roofline)")
+                         "(default steps//8; each event pair costs stream time; 0 = none, no roofline)")
+    ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 2)")
     args = ap.parse_args()
 
     import torch
@@ -155,26 +292,31 @@ def main():
     wl = importlib.import_module("pi_slam_fusion_amd.workloads")
     force_float = 0 if args.int16 else 1
     K, W, N = args.steps, args.warmup, world
-    cam = [4000, 3000, 3000, 3000, 2000, 1500]
-    height = 100.0
+    ev_every = event_every_for(K, args.event_every)
+    strong = args.shard == "strong" and N > 1
+    block = args.shard_block or (2 if strong else 128)
     n_traj = K + W
-    block = 128                                     # spatial-hash cell edge in tiles
     extra = {} if args.fused is None else {"fused": args.fused}
-    opt = pf.default_options(force_float=force_float, scale=args.scale, device=dev,
-                             shard_rank=rank, shard_count=N, shard_block=block, **extra)
-    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt)
 
-    # one sortie per rank; sortie j is flown inside a hash cell owned by rank j
+    def make_map(ff):
+        opt = pf.default_options(force_float=ff, scale=args.scale, device=dev,
+                                 shard_rank=rank, shard_count=N, shard_block=block, **extra)
+        return pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt), opt
+
+    m, opt = make_map(force_float)
+
+    # weak: one sortie per rank, sortie j flown inside a hash cell owned by rank j
+    # strong: one sortie for everybody
     # 16 rows of 20 frames (~850 m x 400 m) fit one 128-tile hash cell; longer runs fly the sortie again
-    base = wl.serpentine(cam, height, n_traj, max_rows=16)
-    if N == 1:
+    base = wl.serpentine(CAM, HEIGHT, n_traj, max_rows=16)
+    if N == 1 or strong:
         prep = base[:20]
-        assert m.prepare(wl.IDENTITY_PLANE, cam, prep)
+        assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
         sorties = [base]
     else:
         span = 6000.0
-        prep = [[x, y, -height, 0, 0, 0, 1] for x in (-span, span) for y in (-span, span)]
-        assert m.prepare(wl.IDENTITY_PLANE, cam, prep)
+        prep = [[x, y, -HEIGHT, 0, 0, 0, 1] for x in (-span, span) for y in (-span, span)]
+        assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
         dims, geo = m.grid()
         ele = geo[4]
         xs = np.array([p[0] for p in base]); ys = np.array([p[1] for p in base])
@@ -193,107 +335,100 @@ def main():
             ox = geo[0] + (cx + 0.5) * block * ele - 0.5 * (xs.max() + xs.min())
             oy = geo[1] + (cy + 0.5) * block * ele - 0.5 * (ys.max() + ys.min())
             sorties.append([[p[0] + ox, p[1] + oy] + p[2:] for p in base])
+    my_sortie = sorties[0] if (N == 1 or strong) else sorties[rank]
 
     # size the tile store for the sortie up front (std::vector::reserve for HBM; `spreadMap` still grows the grid):
     # hipMalloc and the driver's page clearing then happen here, not between two keyframes of the timed region
-    ele_m = m.grid()[1][4]
-    sx = [p[0] for p in sorties[rank]]; sy = [p[1] for p in sorties[rank]]
-    foot = 1.2 * max(cam[0], cam[1]) * height / cam[2]
-    m.reserve_tiles(int(((max(sx) - min(sx) + foot) / ele_m + 2) * ((max(sy) - min(sy) + foot) / ele_m + 2) * 1.1) + 64)
+    def reserve(mm):
+        ele_m = mm.grid()[1][4]
+        sx = [p[0] for p in my_sortie]; sy = [p[1] for p in my_sortie]
+        foot = 1.2 * max(CAM[0], CAM[1]) * HEIGHT / CAM[2]
+        n_all = int(((max(sx) - min(sx) + foot) / ele_m + 2) * ((max(sy) - min(sy) + foot) / ele_m + 2) * 1.1) + 64
+        mm.reserve_tiles(n_all if not strong else n_all // N + n_all // 8 + 64)
+    reserve(m)
 
     # synthetic frames, resident in HBM before the timed region
-    g = torch.Generator(device="cuda"); g.manual_seed(1234 + rank)
+    g = torch.Generator(device="cuda"); g.manual_seed(1234 + (0 if strong else rank))
     frames = [torch.randint(0, 256, (3000, 4000, 3), dtype=torch.uint8, device="cuda", generator=g)
               for _ in range(args.distinct)]
     torch.cuda.synchronize()
 
     # frame routing (untimed): a rank needs a frame's pixels only if the frame's canvas holds one of
     # its tiles; every rank still gets every pose (geometry-only feed) so the grid advances identically
-    def needs_pixels(pose):
-        if N == 1:
-            return True
+    def owned_tiles(pose):
+        """(tiles of the frame's canvas owned by this rank, tiles in the canvas), on the current grid"""
         dims, geo = m.grid()
-        pts = pf.footprint(cam, pf.se3_mul(pf.se3_inverse(wl.IDENTITY_PLANE), pose))
+        pts = pf.footprint(CAM, pf.se3_mul(pf.se3_inverse(wl.IDENTITY_PLANE), pose))
         if pts is None:
-            return False
+            return 0, 0
         inv = 1.0 / geo[4]
         x0 = int(np.floor((pts[:, 0].min() - geo[0]) * inv)); x1 = int(np.ceil((pts[:, 0].max() - geo[0]) * inv))
         y0 = int(np.floor((pts[:, 1].min() - geo[1]) * inv)); y1 = int(np.ceil((pts[:, 1].max() - geo[1]) * inv))
-        return any(pf.tile_owner(opt, x + dims[2], y + dims[3]) == rank for y in range(y0, y1) for x in range(x0, x1))
+        mine = sum(pf.tile_owner(opt, x + dims[2], y + dims[3]) == rank for y in range(y0, y1) for x in range(x0, x1))
+        return mine, (y1 - y0) * (x1 - x0)
 
-    need = [[needs_pixels(sorties[j][k]) for k in range(n_traj)] for j in range(N)]
+    if N == 1:
+        need = [[True] * n_traj]
+    elif strong:
+        need = [[True] * n_traj]            # the library itself skips frames none of whose tiles it owns
+    else:
+        need = [[owned_tiles(sorties[j][k])[0] > 0 for k in range(n_traj)] for j in range(N)]
 
-    def run(lo, hi):
-        for k in range(lo, hi):
-            for j in range(N):
-                if need[j][k]:
-                    ok = m.feed_device(frames[(k + j) % len(frames)].data_ptr(), 3000, 4000, sorties[j][k])
-                else:
-                    ok = m.feed(None, sorties[j][k])
-                assert ok, "frame %d of sortie %d rejected" % (k, j)
-
-    # warm-up with every kernel timed: find the dominant kernel
-    m.profile_enable(1)
-    run(0, W)
-    m.sync()
-    prof = m.profile_read()
-    names = list(prof.keys())
-    dom = max(names, key=lambda n: prof[n]["ms"]) if W > 0 else "warp"
-    m.profile_reset()
-    # timed region: events around that kernel only, every n-th launch
-    m.profile_enable((2 + names.index(dom)) | (args.event_every << 8) if args.event_every else 0)
+    def make_run(mm):
+        def run(lo, hi):
+            for k in range(lo, hi):
+                for j in range(len(sorties)):
+                    if need[j][k]:
+                        ok = mm.feed_device(frames[(k + j) % len(frames)].data_ptr(), 3000, 4000, sorties[j][k])
+                    else:
+                        ok = mm.feed(None, sorties[j][k])
+                    assert ok, "frame %d of sortie %d rejected" % (k, j)
+        return run
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    run(W, W + K)
-    m.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    dt = t1 - t0
+    dt, dom, p, prof = timed_run(m, make_run(m), W, K, ev_every, barrier)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = m.stats()
-    p = m.profile_read()[dom]
-    m.profile_enable(0)
+    total_frames = K if (N == 1 or strong) else N * K
+    dkey = "f32" if force_float else "int16"
 
+    out = None
     if rank == 0:
-        ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("f32" if force_float else "int16", {}).get(dom)
-            except Exception:
-                traffic = None
         out = {
             "metric": "keyframes/sec fused (4000x3000 -> 256^2 tiles, 5-band)",
-            "value": round(N * K / dt, 3), "unit": "keyframes/s", "n_gpus": N, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if force_float else "int16", "data": "synthetic",
+            "value": round(total_frames / dt, 3), "unit": "keyframes/s", "n_gpus": N, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": dkey, "data": "synthetic",
             "config": {"workload": "cfg-2/cfg-A: 4000x3000 BGR8 keyframes, serpentine sortie, Map2D.Scale=%g, "
                                    "5-band Laplacian, %s pyramids, frames resident in HBM" %
                                    (args.scale, "CV_32FC3 (ForceFloat=1)" if force_float else "CV_16SC3"),
-                       "frames_per_rank": K, "tile_sharding": "spatial hash, cell %d tiles" % block if N > 1 else "none",
+                       "frames_per_rank": K,
+                       "tile_sharding": "none" if N == 1 else
+                                        ("one sortie, tiles split by spatial hash, cell %d tiles" % block if strong else
+                                         "replicas: one sortie per rank inside its own hash cell (cell %d tiles)" % block),
                        "rendered_rank0": st["rendered"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "avg_launch_us": round(p["ms"] / max(p["launches"], 1) * 1e3, 2),
-                         "alg_bytes_per_launch": round(p["alg_bytes"] / max(p["launches"], 1)),
-                         "launches": p["launches"], "timed_every": args.event_every},
-            "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (N * K / dt) / N / 1e9, 1),
-            "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in names if prof[n]["launches"]},
+            "roofline": guarded(roofline_record, dom, p, dkey, ev_every),
+            "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
+            "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
         }
+
+    # strong sharding: what a rank renders beyond its share, and the timed seam exchange
+    if strong:
+        sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+        info = guarded(sh.strong_report, pf, m, dist, opt, owned_tiles, base[W:W + K])
+        if rank == 0:
+            out["sharding"] = info
+
+    if rank == 0:
         # measured HBM ceiling on this box (SURVEY 8d): a 1 GiB device-to-device copy, read + write bytes
-        try:
+        def copy_ceiling():
             a_ = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); b_ = torch.empty_like(a_)
             b_.copy_(a_); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -301,20 +436,36 @@ def main():
             for _ in range(10):
                 b_.copy_(a_)
             e1.record(); torch.cuda.synchronize()
-            out["roofline"]["copy_ceiling_GBps"] = round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del a_, b_
-        except Exception:
-            pass
-        if not args.no_cpu:
-            hostf = [f.cpu().numpy() for f in frames[:2]]
-            out["cpu_baseline"] = cpu_baseline(wl, cam, sorties[0], prep, hostf, force_float)
-            allc = cpu_baseline_allcores(force_float)
-            if allc:
-                out["cpu_baseline_allcores"] = allc
-            try:
-                out["map2dcpu_single_band"] = map2dcpu_rates(pf, wl, cam, sorties[0], prep, frames, hostf)
-            except Exception as e:                      # informational: never fail the headline line
-                out["map2dcpu_single_band"] = {"error": str(e)[:200]}
+            return round(10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        cc = guarded(copy_ceiling)
+        if isinstance(out["roofline"], dict) and "error" not in out["roofline"]:
+            out["roofline"]["copy_ceiling_GBps"] = cc
+
+    # the other pyramid type in the same run (the reference's default is CV_16SC3; north_star's parity bar is on fp32)
+    if not args.no_cpu and N == 1:
+        def other_dtype():
+            m2, _ = make_map(1 - force_float)
+            assert m2.prepare(wl.IDENTITY_PLANE, CAM, prep)
+            reserve(m2)
+            dt2, dom2, p2, _ = timed_run(m2, make_run(m2), W, K, ev_every, barrier)
+            k2 = "f32" if not force_float else "int16"
+            rec = {"value": round(K / dt2, 3), "unit": "keyframes/s", "dtype": k2, "ms_per_step": round(dt2 / K * 1e3, 4),
+                   "roofline": roofline_record(dom2, p2, k2, ev_every)}
+            m2.close()
+            return rec
+        out["int16" if force_float else "f32"] = guarded(other_dtype)
+
+    if rank == 0 and not args.no_cpu:
+        hostf = guarded(lambda: [f.cpu().numpy() for f in frames[:2]])
+        if isinstance(hostf, dict):
+            out["cpu_baseline"] = hostf
+        else:
+            out["cpu_baseline"] = guarded(cpu_baseline, wl, my_sortie, prep, hostf, force_float)
+            out["cpu_baseline_allcores"] = guarded(cpu_baseline_allcores, force_float)
+            if N == 1:
+                out["host_feed"] = guarded(host_feed_rate, pf, wl, my_sortie, prep, hostf, force_float)
+                out["map2dcpu_single_band"] = guarded(map2dcpu_rates, pf, wl, my_sortie, prep, frames, hostf)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

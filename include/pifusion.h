@@ -80,8 +80,10 @@ const char* pf_last_error(void);
  * that carry an image are queued and rendered first, Map2D.cpp:42).        */
 int     pf_prepare(pf_map* m, const double plane[7], const double cam[6],
                    int n, const pf_image* imgs, const double* poses7);
-/* Map2D::feed(img, pose), MultiBandMap2DCPU.cpp:288-309.  Host BGR8 frame;
- * the pixels are copied (pinned staging + async H2D) before returning.    */
+/* Map2D::feed(img, pose), MultiBandMap2DCPU.cpp:288-309.  Host BGR8 (or BGRA8) frame; the
+ * rows are copied to HBM as they lie (img->step is kept) by one blocking linear H2D copy, so
+ * the caller may release its pixels when feed returns (the reference keeps a refcounted
+ * cv::Mat instead).                                                          */
 int     pf_feed(pf_map* m, const pf_image* img, const double pose[7]);
 /* Same, frame already resident in HBM (img->data is a device pointer that
  * must stay valid until pf_sync).  thread=0 maps only.                     */

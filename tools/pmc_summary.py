@@ -2,8 +2,11 @@
 """Summarise rocprofv3 output for profiles/.
 
   kernel stats : tools/pmc_summary.py stats <dir with *_kernel_stats.csv> > profiles/<name>.md
-  HBM traffic  : tools/pmc_summary.py traffic <fetch dir> <write dir> <dtype> [profiles/pmc_traffic.json]
+  HBM traffic  : tools/pmc_summary.py traffic <fetch dir> <write dir> <dtype> [profiles/pmc_traffic.json] [<SQ_INSTS_VALU dir>]
   SQ counters  : tools/pmc_summary.py counters <pmc dir> ...
+
+The JSON records the build it was taken at (_meta.git_sha, _meta.kernels_sha = bench.kernels_sha()); bench.py
+reports `roofline.pmc_build.current` = false when the device code has changed since.
 
 Traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE come from
 separate --pmc passes; both are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
@@ -88,16 +91,36 @@ def counter_means(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
 
 
-def traffic(fd, wd, dtype, out):
+def build_meta():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    try:
+        import subprocess
+        sha = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        sha = os.environ.get("PF_GIT_SHA")          # the GPU box has no .git: pass the sha in
+    return {"git_sha": sha, "kernels_sha": bench.kernels_sha(),
+            "how": "tools/profile_round.sh + tools/pmc_summary.py (separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)"}
+
+
+def traffic(fd, wd, dtype, out, vd=None):
     f, nf = counter_means(fd, "FETCH_SIZE")
     w, _ = counter_means(wd, "WRITE_SIZE")
+    v = counter_means(vd, "SQ_INSTS_VALU")[0] if vd else {}
     res = {}
     for k in sorted(set(f) | set(w)):
-        res[k] = int(round(2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024))
+        res[k] = {"traffic": int(round(2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024))}
+        if k in v:
+            res[k]["valu_insts"] = int(round(v[k]))
         print("%-14s launches %5d  fetch(x2) %10.1f KiB  write %10.1f KiB  -> %d B/launch" %
-              (k, nf.get(k, 0), 2 * f.get(k, 0.0), w.get(k, 0.0), res[k]), file=sys.stderr)
+              (k, nf.get(k, 0), 2 * f.get(k, 0.0), w.get(k, 0.0), res[k]["traffic"]), file=sys.stderr)
     if out:
         cur = json.load(open(out)) if os.path.exists(out) else {}
+        meta = build_meta()
+        if cur.get("_meta", {}).get("kernels_sha") != meta["kernels_sha"]:
+            cur = {}                                  # numbers of another build do not mix
+        cur["_meta"] = meta
         cur[dtype] = res
         json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res))
@@ -122,4 +145,5 @@ if __name__ == "__main__":
     elif sys.argv[1] == "counters":
         counters(sys.argv[2:])
     else:
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None,
+                sys.argv[6] if len(sys.argv) > 6 else None)
