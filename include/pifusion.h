@@ -96,6 +96,9 @@ int     pf_sync(pf_map* m);
 /* Map2D::save(filename), MultiBandMap2DCPU.cpp:779-847.  Writes PNG (.png),
  * else binary PPM.                                                         */
 int     pf_save(pf_map* m, const char* filename);
+/* The file leg of save() alone: cv::imwrite(filename, result), MultiBandMap2DCPU.cpp:841.  8-bit BGR in,
+ * PNG (8-bit RGB, deflate) when the name ends in .png/.PNG, binary PPM (P6) otherwise.  No device needed. */
+int     pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols);
 /* save() without the file: whole-mosaic collapse into caller memory.  Call
  * with bgr=NULL to query rows/cols/origin tile.                            */
 int     pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);

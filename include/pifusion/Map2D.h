@@ -69,9 +69,14 @@ template <class SE3> inline void pose7(const SE3& p, double o[7])
     const auto& t = p.get_translation(); const auto& r = p.get_rotation();
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = r.x; o[4] = r.y; o[5] = r.z; o[6] = r.w;
 }
+// row pitch of the caller's image: cv::Mat::step (MatStep converts to size_t) and ImageView::step are carried over,
+// so a ROI of a wider buffer or a row-padded image is read with its own pitch; types without a step member
+// (GSLAM::GImage is always packed, GImage.h:387-389) give 0 = packed
+template <class Img> inline auto step_of(const Img& m, int) -> decltype(size_t(m.step)) { return size_t(m.step); }
+template <class Img> inline size_t step_of(const Img&, long) { return 0; }
 template <class Img> inline pf_image view(const Img& m)
 {
-    pf_image v; v.rows = m.rows; v.cols = m.cols; v.type = m.type() & 0xfff; v.data = m.data; v.step = 0;
+    pf_image v; v.rows = m.rows; v.cols = m.cols; v.type = m.type() & 0xfff; v.data = m.data; v.step = step_of(m, 0);
     return v;
 }
 

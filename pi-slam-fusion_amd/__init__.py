@@ -71,6 +71,7 @@ def lib():
     L.pf_sync.argtypes = [vp]
     L.pf_save.argtypes = [vp, C.c_char_p]
     L.pf_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
+    L.pf_write_image.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
     L.pf_num_levels.argtypes = [vp]
     L.pf_pyramid_type.argtypes = [vp]
     L.pf_grid.argtypes = [vp, ip, dp]
@@ -139,6 +140,12 @@ def perspective_transform(src, dst):
     M = np.zeros(9)
     lib().pf_perspective_transform(s.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), M.ctypes.data_as(C.c_void_p))
     return M.reshape(3, 3)
+
+
+def write_image(filename, bgr):
+    """cv::imwrite leg of save() (MultiBandMap2DCPU.cpp:841): HxWx3 BGR uint8 -> .png / .ppm"""
+    a = np.ascontiguousarray(bgr, dtype=np.uint8)
+    return bool(lib().pf_write_image(filename.encode(), a.ctypes.data, a.shape[0], a.shape[1]))
 
 
 def tile_owner(opt, ix, iy):

@@ -59,6 +59,8 @@ int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { retur
 unsigned pf_queue_size(pf_map* m) { return m ? m->impl.queue_size() : 0; }
 int pf_sync(pf_map* m) { return m && m->impl.sync(); }
 int pf_save(pf_map* m, const char* filename) { return m && filename && m->impl.save(filename); }
+int pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols)
+{ return filename && bgr && rows > 0 && cols > 0 && pf::write_image_file(filename, bgr, rows, cols); }
 int pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return m && rows && cols && tx0 && ty0 && m->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
 

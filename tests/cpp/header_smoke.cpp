@@ -24,7 +24,33 @@ int main()
     if (!map->sync() || map->queueSize() != 0) return 5;
     int n = 0;
     map->draw([&](int, int, const unsigned char* bgr) { n += bgr[0] >= 0; });
-    Map2D::Ele e;
     std::printf("tiles refreshed: %d\n", n);
-    return n > 0 ? 0 : 6;
+    if (n <= 0) return 6;
+
+    // A ROI of a wider buffer (cv::Mat::step > cols * channels) through the C++ face: the row pitch must travel.
+    // Same pixels packed and padded -> the same tiles.
+    {
+        std::vector<unsigned char> packed(480 * 640 * 3), wide(480 * 2100, 7);
+        for (size_t i = 0; i < packed.size(); i++) packed[i] = (unsigned char)((i * 2654435761u) >> 13);
+        for (int y = 0; y < 480; y++) std::copy(packed.begin() + y * 1920, packed.begin() + (y + 1) * 1920, wide.begin() + y * 2100 + 90);
+        std::shared_ptr<Map2D> a = Map2D::create(Map2D::TypeMultiBandCPU, false), b = Map2D::create(Map2D::TypeMultiBandCPU, false);
+        pifusion::ImageView pk(480, 640, PF_8UC3, packed.data()), roi(480, 640, PF_8UC3, wide.data() + 90, 2100);
+        std::deque<std::pair<pifusion::ImageView, pi::SE3d>> fa(1, std::make_pair(pk, pi::SE3d(0, 0, -100, 0, 0, 0.0436194, 0.9990482)));
+        if (!a->prepare(pi::SE3d(), PinHoleParameters(640, 480, 500, 500, 320, 240), fa) ||
+            !b->prepare(pi::SE3d(), PinHoleParameters(640, 480, 500, 500, 320, 240), fa)) return 7;
+        if (!a->feed(pk, fa[0].second) || !b->feed(roi, fa[0].second) || !a->sync() || !b->sync()) return 8;
+        Map2D::Ele ea, eb;
+        int tiles = 0;
+        for (int iy = -4; iy < 12; iy++)
+            for (int ix = -4; ix < 12; ix++) {
+                const bool ha = a->ele(ix, iy, ea), hb = b->ele(ix, iy, eb);
+                if (ha != hb) return 9;
+                if (!ha) continue;
+                tiles++;
+                if (ea.pyr_laplace != eb.pyr_laplace || ea.weights != eb.weights) { std::printf("padded view differs at tile %d,%d\n", ix, iy); return 10; }
+            }
+        std::printf("padded view == packed view on %d tiles\n", tiles);
+        if (!tiles) return 11;
+    }
+    return 0;
 }

@@ -7,7 +7,7 @@ import time
 import numpy as np
 import pytest
 
-from helpers import jitter_poses, map_digest, workloads
+from helpers import compare_maps, jitter_poses, map_digest, workloads
 
 
 def mods(pf):
@@ -61,23 +61,26 @@ def test_dataset_format_roundtrip(pf, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [1, 0])
-def test_bgra_frames_equal_bgr(pf, fused):
-    """The tracker hands BGRA (GImage 8UC4); dropping alpha in the gather == cvtColor BGRA2BGR first."""
+def test_bgra_frames_equal_bgr(pf, orc, fused):
+    """The tracker hands BGRA (GImage 8UC4); dropping alpha in the gather == cvtColor BGRA2BGR first
+    (TrackerOpt.cpp:376-380), i.e. the oracle fed the BGR pixels."""
     wl = workloads()
     cam = [640, 480, 500, 500, 320, 240]
     poses = jitter_poses(5, seed=8)
     a = pf.Map2D.create(pf.TypeMultiBandCPU, False, fused=fused); b = pf.Map2D.create(pf.TypeMultiBandCPU, False, fused=fused)
-    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses)
+    o = orc.OracleMap()
+    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
     for k, p in enumerate(poses):
         bgr = wl.noise_frame(480, 640, 60 + k)
         bgra = np.concatenate([bgr, wl.noise_frame(480, 640, 900 + k)[:, :, :1]], axis=2)
-        assert a.feed(bgr, p) and b.feed(bgra, p)
+        assert a.feed(bgr, p) and b.feed(bgra, p) and o.feed(bgr, p)
     a.sync(); b.sync()
+    assert compare_maps(b, o) == []
     assert map_digest(a) == map_digest(b)
 
 
 @pytest.mark.gpu
-def test_live_wire_cfg4(pf, tmp_path):
+def test_live_wire_cfg4(pf, orc, tmp_path):
     """BASELINE cfg-4 boundary: a producer thread pushes (frame, pose) through DataTrans, the
     TestSystem loop feeds a thread=true map while queueSize() < 2; no drops, tiles equal the
     synchronous run."""
@@ -108,6 +111,13 @@ def test_live_wire_cfg4(pf, tmp_path):
         img, p = d.load(k); assert s.feed(img, p)
     s.sync()
     assert map_digest(m) == map_digest(s)
+    # ... and the oracle: the threaded map renders its prepare frames first (Map2D.cpp:42, .cpp:606-615), then the wire's
+    o = orc.OracleMap()
+    assert o.prepare(d.plane, d.camera, [p for _, p in first])
+    for k in range(len(d)):
+        img, p = d.load(k); assert o.feed(img, p)
+    assert compare_maps(m, o) == []
+    assert np.array_equal(m.save_to_memory()[0], o.save()[0])
 
 
 def test_overlay_message_format(pf):

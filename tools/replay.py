@@ -29,7 +29,7 @@ n0 = min(a.prepare, len(ds))
 first = [ds.load(k) for k in range(n0)]
 print("Loaded %d frames." % n0)
 assert m.prepare(ds.plane, ds.camera, [p for _, p in first], images=[i for i, _ in first] if a.thread else None)
-it = iter(range(0 if not a.thread else n0, len(ds)))
+it = iter(range(n0, len(ds)))          # obtainFrame consumed the prepare frames (a thread=0 map never renders them, Map2D.cpp:42)
 t0 = time.perf_counter()
 fed = dt.feed_loop(m, lambda: (lambda k: None if k is None else ds.load(k))(next(it, None)), a.fps)
 m.sync()
