@@ -88,6 +88,10 @@ int     pf_feed(pf_map* m, const pf_image* img, const double pose[7]);
 /* Same, frame already resident in HBM (img->data is a device pointer that
  * must stay valid until pf_sync).  thread=0 maps only.                     */
 int     pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]);
+/* Test hook (no reference counterpart): the bytes of the host frame most recently copied by pf_feed / pf_prepare,
+ * read back from HBM -- (rows-1)*step + cols*channels of them.  Returns the byte count (out may be NULL to query it),
+ * -1 when there is none.  Lets a test prove that a row-padded frame arrived byte for byte.                        */
+long    pf_debug_read_last_frame(pf_map* m, void* out, size_t cap);
 /* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
 unsigned pf_queue_size(pf_map* m);
 /* drain the feed queue and the device stream (no reference counterpart:

@@ -68,6 +68,7 @@ def lib():
     L.pf_feed.argtypes = [vp, C.POINTER(Image), dp]
     L.pf_feed_device.argtypes = [vp, C.POINTER(Image), dp]
     L.pf_queue_size.argtypes = [vp]; L.pf_queue_size.restype = C.c_uint
+    L.pf_debug_read_last_frame.argtypes = [vp, vp, C.c_size_t]; L.pf_debug_read_last_frame.restype = C.c_long
     L.pf_sync.argtypes = [vp]
     L.pf_save.argtypes = [vp, C.c_char_p]
     L.pf_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
@@ -216,6 +217,14 @@ class Map2D:
         p, pp = _pose(pose)
         im = Image(rows, cols, PF_8UC3, data_ptr, step)
         return bool(lib().pf_feed_device(self._h, C.byref(im), pp))
+
+    def read_last_frame(self):
+        """test hook: bytes of the most recently uploaded host frame as they lie in HBM"""
+        n = lib().pf_debug_read_last_frame(self._h, None, 0)
+        if n < 0:
+            return None
+        out = np.empty(n, np.uint8)
+        return out if lib().pf_debug_read_last_frame(self._h, out.ctypes.data, n) == n else None
 
     def queueSize(self):
         return int(lib().pf_queue_size(self._h))

@@ -1,6 +1,7 @@
 // fusion_map.cpp -- host engine: prepare / feed / renderFrame / blend / save on
 // the GPU, following the control flow of Map2DFusion/MultiBandMap2DCPU.cpp.
 #include "fusion_map.hpp"
+#include "warp_index.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -373,7 +374,9 @@ bool FusionMap::upload(const pf_image* img, int slot)
     // before the kernel that reads it is enqueued.  The map's streams are non-blocking, so this does not wait for
     // kernels in flight.
     const size_t row = (size_t)img->cols * (img->type == PF_8UC4 ? 4 : 3), step = img->step ? img->step : row;
-    HIP_OK(hipMemcpy(slots_[slot].dev, img->data, (size_t)(img->rows - 1) * step + row, hipMemcpyHostToDevice));
+    const size_t bytes = (size_t)(img->rows - 1) * step + row;          // == frame_bytes(): what the kernels may read
+    HIP_OK(hipMemcpy(slots_[slot].dev, img->data, bytes, hipMemcpyHostToDevice));
+    last_slot_ = slot; last_bytes_ = bytes;
     return true;
 }
 
@@ -403,6 +406,10 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
                     set_error("feed: row step smaller than a row, or frame of 2 GiB or more");
                     return false;
                 }
+                if (frame_bytes(img->rows, img->cols, (long)(img->step ? img->step : row_bytes), f.cn) < 8) {
+                    set_error("feed: frame smaller than 8 bytes");      // the warp loads 8 bytes per source row (warp_index.hpp)
+                    return false;
+                }
                 if (device_ptr) {
                     if (thread_) { set_error("pf_feed_device needs a thread=0 map"); return false; }
                     f.ext = (const uint8_t*)img->data; f.step = img->step ? (long)img->step : (long)img->cols * f.cn;
@@ -428,6 +435,15 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
     }
     std::lock_guard<std::mutex> l(mu_);
     return render_frame(f);
+}
+
+// test hook: the bytes of the most recently uploaded host frame as they lie in HBM
+long FusionMap::read_back_last_frame(void* out, size_t cap)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || last_slot_ < 0 || !set_device()) return -1;
+    if (out && cap >= last_bytes_ && hipMemcpy(out, slots_[last_slot_].dev, last_bytes_, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long)last_bytes_;
 }
 
 unsigned FusionMap::queue_size() { std::lock_guard<std::mutex> q(qmu_); return (unsigned)queue_.size(); }

@@ -80,6 +80,7 @@ public:
     bool prepare(const double plane[7], const double cam[6], int n, const pf_image* imgs, const double* poses7);
     bool feed(const pf_image* img, const double pose[7], bool device_ptr);
     unsigned queue_size();
+    long read_back_last_frame(void* out, size_t cap);
     bool sync();
     bool save(const char* filename);
     bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
@@ -180,6 +181,7 @@ private:
 
     // frame staging + feed queue
     std::vector<FrameSlot> slots_;
+    int    last_slot_ = -1; size_t last_bytes_ = 0;       // most recent upload (read_back_last_frame)
     std::mutex qmu_;
     std::condition_variable qcv_, idle_cv_;
     std::deque<QueuedFrame> queue_;

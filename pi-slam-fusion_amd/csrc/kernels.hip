@@ -13,6 +13,7 @@
 //   k_blend_* / k_collapse  :77-146 Ele::blend, :836 save's collapse
 //   k_mosaic_gather / k_save_finish  :806-840 save
 #include "kernels.hpp"
+#include "warp_index.hpp"
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -20,38 +21,7 @@
 namespace pf {
 
 // ---------------------------------------------------------------- helpers
-__device__ __forceinline__ int border_reflect(int p, int len)          // BORDER_REFLECT  fedcba|abcdefgh|hgfedcb
-{
-    if ((unsigned)p < (unsigned)len) return p;
-    if (len == 1) return 0;
-    const int m = 2 * len;
-    int q = p % m;
-    if (q < 0) q += m;
-    return q < len ? q : m - 1 - q;
-}
-__device__ __forceinline__ int border_reflect101(int p, int len)       // BORDER_REFLECT_101 gfedcb|abcdefgh|gfedcba
-{
-    if ((unsigned)p < (unsigned)len) return p;
-    if (len == 1) return 0;
-    const int m = 2 * len - 2;
-    int q = p % m;
-    if (q < 0) q += m;
-    return q < len ? q : m - q;
-}
-// the same two maps for -len <= p < 2*len (one reflection, no division): everything a canvas up to three
-// frames wide asks for.  ~p == -p-1.
-__device__ __forceinline__ bool reflect_is_near(int p, int len) { return (unsigned)(p + len) < 3u * (unsigned)len; }
-__device__ __forceinline__ int border_reflect_near(int p, int len)
-{
-    const int q = p ^ (p >> 31);
-    return min(q, 2 * len - 1 - q);
-}
-__device__ __forceinline__ int border_reflect101_near(int p, int len)
-{
-    const int q = p < 0 ? -p : p;
-    return len == 1 ? 0 : min(q, 2 * len - 2 - q);
-}
-__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+// border maps, saturate_cast<short> and the warp's source addressing: warp_index.hpp (shared with the host-side check)
 __device__ __forceinline__ double clamp_int_range(double v)
 {
     v = (v < (double)INT_MAX) ? v : (double)INT_MAX;     // std::min((double)INT_MAX, v)
@@ -333,7 +303,7 @@ constexpr int LBW = 64, LAW = LBW + 7, LQW = LBW / 2 + 2;      // block width, s
 struct LevelOffsets { uint32_t lap_off, w_off, top_lap_off, top_w_off; };   // byte offsets inside a tile slot
 struct FusedWarp {
     double M[9];            // destination -> source map
-    long   total;           // bytes in the frame (srows * sstep)
+    long   total;           // bytes of the frame that may be read (frame_bytes: the last row ends at its last pixel)
     const float* wmap;      // srows x scols radial weight plane (the reference's weightImage)
     int    srows, scols, sstep, cn;
     int    plain;           // host-checked: |M| entries < 2^400 and the frame is at most 32767 px on a side, so W
@@ -381,7 +351,6 @@ struct WarpTaps {
     int      X, Y;                   // 1/32-px source coordinate (the low 5 bits are the bilinear fractions)
     uint32_t flags;
 };
-constexpr uint32_t kT0Hi = 1, kT1Hi = 2, kBack0 = 2, kBack1 = 5, kInb = 1u << 8;   // flags: tap = high pixel, byte shifts, weight in bounds
 
 __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
 {
@@ -433,38 +402,18 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     // Frames are < 2 GiB and rows/steps fit 24 bits: 32-bit unsigned offsets from the frame base, full-rate
     // 24-bit multiplies.
     const int cn = a.cn;                                // 3 (BGR) or 4 (BGRA, alpha skipped)
-    const uint32_t total = (uint32_t)a.total, step = (uint32_t)a.sstep;
-    uint32_t off0, off1;
     // strictly inside the frame and not on its last two rows: both 8-byte reads stay inside the buffer
     const int ux = X >> 5, uy = Y >> 5;
-    const bool fast = (unsigned)ux < (unsigned)(a.scols - 1) && (unsigned)uy < (unsigned)(a.srows - 2);
-    if (a.plain && __builtin_amdgcn_ballot_w64(!fast) == 0) {
-        off0 = (uint32_t)(__mul24(uy, a.sstep) + __mul24(cn, ux));
-        off1 = off0 + step;
-        flags |= kT1Hi;
-    } else {
-        const int sx = sat_short(ux), sy = sat_short(uy);
-        int sx0, sx1, sy0, sy1;
-        const bool near = a.plain && reflect_is_near(sx, a.scols) && reflect_is_near(sx + 1, a.scols) &&
-                          reflect_is_near(sy, a.srows) && reflect_is_near(sy + 1, a.srows);
-        if (__builtin_amdgcn_ballot_w64(!near) == 0) {        // canvas pixels next to the frame: one reflection
-            sx0 = border_reflect_near(sx, a.scols); sx1 = border_reflect_near(sx + 1, a.scols);
-            sy0 = border_reflect_near(sy, a.srows); sy1 = border_reflect_near(sy + 1, a.srows);
-        } else {
-            sx0 = border_reflect(sx, a.scols); sx1 = border_reflect(sx + 1, a.scols);
-            sy0 = border_reflect(sy, a.srows); sy1 = border_reflect(sy + 1, a.srows);
-        }
-        // after BORDER_REFLECT the two taps of a row are the same or adjacent pixels
-        const int xbase = sx0 < sx1 ? sx0 : sx1;
-        if (sx0 != xbase) flags |= kT0Hi;
-        if (sx1 != xbase) flags |= kT1Hi;
-        off0 = (uint32_t)(__mul24(sy0, a.sstep) + __mul24(cn, xbase));
-        off1 = (uint32_t)(__mul24(sy1, a.sstep) + __mul24(cn, xbase));
-        // last bytes of the frame: never read past it -- read earlier and shift
-        const uint32_t back0 = off0 + 8 > total ? off0 + 8 - total : 0u, back1 = off1 + 8 > total ? off1 + 8 - total : 0u;
-        off0 -= back0; off1 -= back1;
-        flags |= back0 << kBack0 | back1 << kBack1;
+    TapAddr ta;
+    if (a.plain && __builtin_amdgcn_ballot_w64(!tap_is_fast(ux, uy, a.srows, a.scols)) == 0)
+        ta = tap_addr_fast(ux, uy, a.sstep, cn);
+    else {
+        // canvas pixels next to the frame, decided per wave: one reflection, no division
+        const bool near = a.plain && __builtin_amdgcn_ballot_w64(!tap_is_near(ux, uy, a.srows, a.scols)) == 0;
+        ta = tap_addr_border(ux, uy, near, a.srows, a.scols, a.sstep, cn, (uint32_t)a.total);
     }
+    const uint32_t off0 = ta.off0, off1 = ta.off1;
+    flags |= ta.flags;
     const u2 b0 = *(const u2*)(src + off0), b1 = *(const u2*)(src + off1);
     t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y;
     t.X = X; t.Y = Y; t.flags = flags;
@@ -493,9 +442,8 @@ __device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
         const bool t0hi = flags & kT0Hi, t1hi = flags & kT1Hi;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            uint64_t bits = (uint64_t)(j ? t.hi1 : t.hi0) << 32 | (j ? t.lo1 : t.lo0);
-            bits >>= 8 * ((flags >> (j ? kBack1 : kBack0)) & 7);
-            const uint32_t lo = (uint32_t)bits, hi = __builtin_amdgcn_perm((uint32_t)(bits >> 32), (uint32_t)bits, hisel);
+            uint32_t lo, hi;
+            row_taps(j ? t.lo1 : t.lo0, j ? t.hi1 : t.hi0, (flags >> (j ? kBack1 : kBack0)) & 7, cn, lo, hi);
             const float l0 = (float)(lo & 0xff), l1 = (float)((lo >> 8) & 0xff), l2 = (float)((lo >> 16) & 0xff);
             const float h0 = (float)(hi & 0xff), h1 = (float)((hi >> 8) & 0xff), h2 = (float)((hi >> 16) & 0xff);
             v[2 * j][0] = t0hi ? h0 : l0; v[2 * j][1] = t0hi ? h1 : l1; v[2 * j][2] = t0hi ? h2 : l2;
@@ -1151,7 +1099,7 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     FusedWarp w{};
     if (wa) {
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
-        w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
+        w.total = frame_bytes(wa->srows, wa->scols, wa->sstep, wa->src_cn); w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
         w.plain = plain_homography(*wa);
     }
@@ -1191,7 +1139,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     FusedWarp w{};
     if (wa) {
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
-        w.total = (long)wa->srows * wa->sstep; w.wmap = wa->wmap;
+        w.total = frame_bytes(wa->srows, wa->scols, wa->sstep, wa->src_cn); w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
         w.plain = plain_homography(*wa);
     }

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void k_single2(const uint8_t* __restrict__ src
         SingleTaps t;
         single_coords(a, col, y, plain, t.X, t.Y);
         const int ux = t.X >> 5, uy = t.Y >> 5;
-        const bool in = (unsigned)ux < (unsigned)(a.scols - 1) && (unsigned)uy < (unsigned)(a.srows - 2);
+        const bool in = (unsigned)ux < (unsigned)(a.scols - 1) && (unsigned)uy < (unsigned)(a.srows < 2 ? 0 : a.srows - 2);
         t.fast = plain && __builtin_amdgcn_ballot_w64(!in) == 0;
         t.lo0 = t.hi0 = t.lo1 = t.hi1 = t.wa = 0;
         if (t.fast) {

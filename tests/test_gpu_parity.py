@@ -229,20 +229,57 @@ def test_stress_geometry_8000x6000_7band(pf, orc, force_float):
     assert compare_maps(g, o) == []
 
 
-def test_row_padded_frames(pf):
-    """cv::Mat::step > cols*channels (a ROI of a wider buffer) is honoured by the H2D copy."""
+def test_row_padded_frames(pf, orc):
+    """cv::Mat::step > cols*channels (a ROI of a wider buffer) is honoured by the H2D copy: the frame lies in HBM
+    byte for byte as the caller holds it (checked by reading the staging slot back after every feed, before any
+    comparison of results), and the map equals both a map fed the packed pixels and the oracle."""
     wl = workloads()
     cam = [640, 480, 500, 500, 320, 240]
     poses = jitter_poses(3, seed=4)
     a = pf.Map2D.create(pf.TypeMultiBandCPU, False); b = pf.Map2D.create(pf.TypeMultiBandCPU, False)
-    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses)
+    o = orc.OracleMap()
+    assert a.prepare(wl.IDENTITY_PLANE, cam, poses) and b.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
     for k, p in enumerate(poses):
         wide = wl.noise_frame(480, 700, 70 + k)
         view = wide[:, 30:670]                         # 640 columns, row step 2100 bytes
         assert view.strides[0] == 2100 and not view.flags["C_CONTIGUOUS"]
-        assert a.feed(view, p) and b.feed(np.ascontiguousarray(view), p)
+        assert a.feed(view, p)
+        got = a.read_last_frame()
+        assert got is not None and got.size == 479 * 2100 + 1920
+        flat = wide.reshape(-1)[90:90 + got.size]      # the caller's bytes from the view's first pixel on, padding included
+        assert np.array_equal(got, flat), "strided frame %d: %d bytes differ in HBM" % (k, int((got != flat).sum()))
+        packed = np.ascontiguousarray(view)
+        assert b.feed(packed, p) and o.feed(packed, p)
+        assert np.array_equal(b.read_last_frame(), packed.reshape(-1))
     a.sync(); b.sync()
+    assert compare_maps(a, o) == []
     assert map_digest(a) == map_digest(b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 64), (2, 48), (40, 1), (3, 3)])
+def test_degenerate_frame_shapes(pf, orc, shape):
+    """frames of one row / one column / a few pixels: every canvas pixel takes the border paths (the fast path's
+    `row < rows-2` test must not wrap for a one-row frame; found by tests/cpp/warp_index_check.cpp)"""
+    wl = workloads()
+    rows, cols = shape
+    cam = [cols, rows, 40.0, 40.0, cols / 2.0, rows / 2.0]
+    poses = [[0.7 * k, 0.3 * k, -100.0] + wl.quat_axis((0, 0, 1), 0.2 * k) for k in range(3)]
+    for ff in (0, 1):
+        g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=ff); o = orc.OracleMap(force_float=ff)
+        assert g.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
+        for k, p in enumerate(poses):
+            img = wl.noise_frame(rows, cols, 500 + k)
+            assert g.feed(img, p) == o.feed(img, p)
+        assert compare_maps(g, o) == []
+    s = pf.Map2D.create(pf.TypeCPU, False); so = orc.OracleMap(single_band=True)
+    assert s.prepare(wl.IDENTITY_PLANE, cam, poses) and so.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        img = wl.noise_frame(rows, cols, 500 + k)
+        assert s.feed(img, p) == so.feed(img, p)
+    assert s.tiles() == so.tiles()
+    for t in so.tiles():
+        assert np.array_equal(s.tile_bgra(*t), so.tile_bgra(*t))
 
 
 @pytest.mark.gpu
