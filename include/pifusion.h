@@ -92,6 +92,9 @@ int     pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]);
  * read back from HBM -- (rows-1)*step + cols*channels of them.  Returns the byte count (out may be NULL to query it),
  * -1 when there is none.  Lets a test prove that a row-padded frame arrived byte for byte.                        */
 long    pf_debug_read_last_frame(pf_map* m, void* out, size_t cap);
+/* Diagnostics (PF_STAMP=1 selects a stamped instantiation of the level kernel; tools/stamp_phases.py): in-kernel clock
+ * stamps of the most recent launch, 8 uint64 per workgroup.  Returns the workgroup count.                            */
+int     pf_debug_phase_stamps(unsigned long long* out, int cap_blocks);
 /* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
 unsigned pf_queue_size(pf_map* m);
 /* drain the feed queue and the device stream (no reference counterpart:

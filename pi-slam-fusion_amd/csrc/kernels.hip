@@ -536,6 +536,17 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
         const int r = idx / LAW, c = idx - r * LAW;
         return r * (2 * LAWH) + (c & 1) * LAWH + (c >> 1);
     };
+    if constexpr (SPLIT && LAH * LAW <= 6 * LNT) {
+        // the whole tile in one round: six loads per thread in flight before the first LDS store.  These workgroups do
+        // nothing but wait for GW_i (written by the previous launch, served from the Infinity Cache or HBM): two
+        // dependent rounds of four loads held a workgroup slot for ~9000 cycles (tools/stamp_phases.py).
+        const int i0 = tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT, i4 = i3 + LNT, i5 = i4 + LNT;
+        const Px t0 = gin[gaddr(i0)], t1 = gin[gaddr(i1)], t2 = gin[gaddr(i2)], t3 = gin[gaddr(i3)], t4 = gin[gaddr(i4)], t5 = gin[gaddr(i5)];
+        Aflat[laddr(i0)] = t0; Aflat[laddr(i1)] = t1; Aflat[laddr(i2)] = t2; Aflat[laddr(i3)] = t3; Aflat[laddr(i4)] = t4;
+        if (i5 < LAH * LAW) Aflat[laddr(i5)] = t5;
+        static_assert(LAH * LAW > 5 * LNT, "i4 is always inside the tile");
+        return;
+    }
 #pragma unroll
     for (int base = 0; base < LAH * LAW; base += 4 * LNT) {
         if (base + begin >= LAH * LAW) break;
@@ -750,11 +761,25 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
 //      serves the four pyrUp parities; one tile-table entry and two 8-byte weight loads per
 //      thread, prefetched after A
 // LDS: A + B only (54 KB fp32 / 40.6 KB int16).
-template <bool F32, int LBH, int LNT>
+// diagnostic build only (PF_STAMP=1, tools/stamp_phases.py): s_memtime at the phase boundaries of a workgroup, written by
+// its first lane to a buffer nothing else reads.  The stamped kernel is a separate instantiation; the product kernel
+// carries no stamp code.
+__device__ __forceinline__ void phase_stamp(unsigned long long* st, int slot)
+{
+    if (st) {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+        if (threadIdx.x == 0) st[slot] = t;
+    }
+}
+
+template <bool F32, int LBH, int LNT, bool STAMP = false>
 __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
                                              const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
-                                             PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table, const int b)
+                                             PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table, const int b,
+                                             unsigned long long* stamps = nullptr)
 {
+    if (STAMP) phase_stamp(stamps, 0);
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
@@ -817,7 +842,9 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     } else {
         stage_from_hbm<F32, LAH, LNT, true>(&A[0][0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
     }
+    if (STAMP) phase_stamp(stamps, 1);
     lds_barrier();
+    if (STAMP) phase_stamp(stamps, 2);
     if (g.ablate & 2) return;
 
     // stored weights of the quad: in flight during stage B
@@ -941,10 +968,17 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             }
         }
     }
+    if (STAMP) phase_stamp(stamps, 3);
     lds_barrier();
+    if (STAMP) phase_stamp(stamps, 4);
     if (g.ablate & 4) return;
 
     // ---- D: 2x2 quad, Laplacian + max-weight select
+    if (STAMP) {
+        // the stamped build ends every path of stage D here
+        struct AtExit { unsigned long long* st; __device__ ~AtExit() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(st, 5); } } at_exit{ stamps };
+        (void)at_exit;
+    }
     if (!ent) return;
     const Px g00 = A[2 * qy + 4][0][qx + 2], g01 = A[2 * qy + 4][1][qx + 2];
     const Px g10 = A[2 * qy + 5][0][qx + 2], g11 = A[2 * qy + 5][1][qx + 2];
@@ -1051,18 +1085,33 @@ struct LevelJob {
     int first;                 // first block id
     int from_warp;             // level 0: stage A is the warp of the launch's frame
 };
-struct LevelBatch { int njobs; LevelJob job[kMaxLevels]; };
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential; LevelJob job[kMaxLevels]; };      // job[k].first, k >= 1: block offset among the upper-level jobs
 
-template <bool F32, int LBH, int LNT>
-__global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src)
+template <bool F32, int LBH, int LNT, bool STAMP = false>
+__global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
-    int j = 0;
-    for (int k = 1; k < batch.njobs; k++) if ((int)blockIdx.x >= batch.job[k].first) j = k;
+    // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
+    // when there is one) or to the upper-level jobs: last in the grid by default, or (PF_INTERLEAVE_JOBS, diagnostics)
+    // spread evenly between the first job's groups.
+    const int g = (int)blockIdx.x >> 3, lane8 = (int)blockIdx.x & 7;
+    const int ug = batch.upper_groups, tg = batch.total_groups;
+    int u0 = (int)(((long)g * ug) / tg), u1 = (int)(((long)(g + 1) * ug) / tg);
+    if (batch.sequential) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // diagnostics: upper levels last
+    int j = 0, b;
+    if (u1 > u0) {                                            // an upper-level group
+        b = u0 * 8 + lane8;
+        j = 1;
+        for (int k = 2; k < batch.njobs; k++) if (b >= batch.job[k].first) j = k;
+        b -= batch.job[j].first;
+    } else
+        b = (g - u0) * 8 + lane8;
     const LevelJob& J = batch.job[j];
-    const int nblk = J.g.nbx * J.g.nby, b = (int)blockIdx.x - J.first;
+    const int nblk = J.g.nbx * J.g.nby;
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
-    level3_block<F32, LBH, LNT>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                J.table, xcd_order(b, nblk));
+    unsigned long long* st = nullptr;
+    if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
+    level3_block<F32, LBH, LNT, STAMP>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
+                                       J.table, xcd_order(b, nblk), st);
 }
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1116,12 +1165,16 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
 }
 
 
+static unsigned long long* g_stamp_buf = nullptr;
+static int g_stamp_blocks = 0;
+constexpr int kStampBlocks = 1 << 16;
+
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
 {
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     constexpr int BH = 32;
     LevelBatch batch{};
-    int nblocks = 0;
+    int first_blocks = 0, upper_blocks = 0;
     for (int k = 0; k < njobs; k++) {
         const LevelLaunch& q = jobs[k];
         LevelJob& J = batch.job[batch.njobs];
@@ -1131,10 +1184,18 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
-        J.first = nblocks;
-        nblocks += (J.g.nbx * J.g.nby + 7) & ~7;
+        // job 0 has its own block numbering, jobs 1.. share one (see k_levels)
+        const int padded = (J.g.nbx * J.g.nby + 7) & ~7;
+        if (batch.njobs == 0) { J.first = 0; first_blocks = padded; }
+        else { J.first = upper_blocks; upper_blocks += padded; }
         batch.njobs++;
     }
+    const int nblocks = first_blocks + upper_blocks;
+    batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8;
+    // measured on MI355X (tools/ab.sh, cfg-A fp32): upper levels dealt between the level-0 groups 156 us per launch, upper
+    // levels last 151 us -- a latency-bound workgroup in a slot costs the level-0 phase more than the tail costs
+    static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
+    batch.sequential = !interleave;
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {
@@ -1143,8 +1204,29 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
         w.plain = plain_homography(*wa);
     }
-    if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
-    else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
+    static const bool stamp = getenv("PF_STAMP") != nullptr;
+    if (stamp) {
+        if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
+        if (g_stamp_buf && nblocks <= kStampBlocks) {
+            (void)hipMemsetAsync(g_stamp_buf, 0, (size_t)kStampBlocks * 64, s);
+            g_stamp_blocks = nblocks;
+            if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, g_stamp_buf);
+            else         hipLaunchKernelGGL((k_levels<false, BH, 512, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, g_stamp_buf);
+            return;
+        }
+    }
+    if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src, (unsigned long long*)nullptr);
+    else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src, (unsigned long long*)nullptr);
+}
+
+// diagnostics: the stamps of the most recent PF_STAMP launch (8 u64 per workgroup: start, A done, barrier 1 passed, B done,
+// barrier 2 passed, D done + stores drained, job index, XCC id); returns the workgroup count
+int read_phase_stamps(unsigned long long* out, int cap_blocks)
+{
+    if (!g_stamp_buf || !g_stamp_blocks) return 0;
+    const int n = g_stamp_blocks < cap_blocks ? g_stamp_blocks : cap_blocks;
+    if (out && hipMemcpy(out, g_stamp_buf, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 // ------------------------------------------------------------------ blend

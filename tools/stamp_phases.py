@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where a workgroup of the level kernel spends its life, measured in the real mix (diagnostic build: PF_STAMP=1
+selects a stamped instantiation of k_levels; the product kernel carries no stamps).
+usage: PF_STAMP=1 python tools/stamp_phases.py [--int16] [--frames N]"""
+import argparse, ctypes as C, importlib, os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import bench
+import numpy as np
+ap = argparse.ArgumentParser(); ap.add_argument("--int16", action="store_true"); ap.add_argument("--frames", type=int, default=60)
+a = ap.parse_args()
+assert os.environ.get("PF_STAMP"), "run with PF_STAMP=1"
+import torch
+pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")
+cam = bench.CAM
+poses = wl.serpentine(cam, 100.0, a.frames + 20)
+m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=0 if a.int16 else 1)
+assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+fr = [torch.randint(0, 256, (cam[1], cam[0], 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+torch.cuda.synchronize()
+for k in range(a.frames + 20):
+    m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k])
+    if k == a.frames + 18:
+        pass
+# the last full launch's stamps are overwritten by the flush launches of sync(): read before syncing the pipeline
+torch.cuda.synchronize()
+L = pf.lib(); L.pf_debug_phase_stamps.argtypes = [C.c_void_p, C.c_int]
+import time; time.sleep(0.2)
+n = L.pf_debug_phase_stamps(None, 1 << 16)
+buf = np.zeros((n, 8), np.uint64)
+assert L.pf_debug_phase_stamps(buf.ctypes.data, n) == n
+buf = buf[buf[:, 0] > 0]
+t0 = buf[:, 0].min()
+names = ["A (stage + warp)", "wait at barrier 1", "B (pyrDown)", "wait at barrier 2", "D (Laplacian, select, stores drained)"]
+print("%d stamped workgroups; launch span %.1f us at 100 MHz-independent shader clock (ticks %d)" % (len(buf), 0, int(buf[:, 5].max() - t0)))
+for job in sorted(set(buf[:, 6].astype(int))):
+    b = buf[buf[:, 6] == job].astype(np.int64)
+    d = np.diff(b[:, :6], axis=1)
+    life = b[:, 5] - b[:, 0]
+    print("job %d: %5d workgroups, lifetime mean %7.0f ticks (min %d, max %d)" % (job, len(b), life.mean(), life.min(), life.max()))
+    for i, nm in enumerate(names):
+        print("    %-40s mean %7.0f  median %7.0f  p90 %7.0f  = %4.1f %% of lifetime" % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
+    start = b[:, 0] - t0
+    print("    starts: first %d, median %d, last %d; ends: median %d, last %d" % (start.min(), np.median(start), start.max(), np.median(b[:, 5] - t0), (b[:, 5] - t0).max()))
