@@ -270,10 +270,6 @@ def main():
     ap.add_argument("--event-every", type=int, default=None,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
                          "(default steps//8; each event pair costs stream time; 0 = none, no roofline)")
-    ap.add_argument("--preroll-ms", type=float, default=400.0,
-                    help="untimed: keep the GPU busy on a scratch map for this long before the W warm-up steps, so that "
-                         "a short run (the driver's --steps 20 --warmup 5 is 5 ms of GPU work) is measured at the clocks "
-                         "a sortie runs at, not during the power-state ramp (0 = off)")
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 2)")
     args = ap.parse_args()
@@ -399,20 +395,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def preroll(ff):
-        if args.preroll_ms <= 0:
-            return 0
-        ms, _ = make_map(ff)
-        assert ms.prepare(wl.IDENTITY_PLANE, CAM, base[:20])
-        t0, n = time.perf_counter(), 0
-        while (time.perf_counter() - t0) * 1e3 < args.preroll_ms:
-            for _ in range(16):
-                ms.feed_device(frames[n % len(frames)].data_ptr(), 3000, 4000, pose_at(base, n)); n += 1
-            ms.sync()
-        ms.close()
-        return n
-
-    n_pre = preroll(force_float)
     dt, dom, p, prof = timed_run(m, make_run(m), W, K, ev_every, barrier)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -436,8 +418,7 @@ def main():
                        "tile_sharding": "none" if N == 1 else
                                         ("one sortie, tiles split by spatial hash, cell %d tiles" % block if strong else
                                          "replicas: one sortie per rank inside its own hash cell (cell %d tiles)" % block),
-                       "rendered_rank0": st["rendered"],
-                       "preroll": "%d untimed frames on a scratch map (%g ms) before the warm-up steps" % (n_pre, args.preroll_ms)},
+                       "rendered_rank0": st["rendered"]},
             "roofline": guarded(roofline_record, dom, p, dkey, ev_every),
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
@@ -471,7 +452,6 @@ def main():
             m2, _ = make_map(1 - force_float)
             assert m2.prepare(wl.IDENTITY_PLANE, CAM, prep)
             reserve(m2)
-            preroll(1 - force_float)
             dt2, dom2, p2, _ = timed_run(m2, make_run(m2), W, K, ev_every, barrier)
             k2 = "f32" if not force_float else "int16"
             rec = {"value": round(K / dt2, 3), "unit": "keyframes/s", "dtype": k2, "ms_per_step": round(dt2 / K * 1e3, 4),

@@ -106,6 +106,7 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     if (single_band_) { lay_.f32 = 0; lay_.lap_off[0] = 0; lay_.w_off[0] = 0; lay_.slot_bytes = kElePixels * kElePixels * 4; }
     store_.configure(lay_.slot_bytes);
     if (opt_.max_queue <= 0) opt_.max_queue = 20;
+    table_zero_copy_ = std::getenv("PF_TABLE_COPY") == nullptr;        // PF_TABLE_COPY=1: the round-1 form (H2D copy per keyframe), for A/B
     if (opt_.shard_count < 1) opt_.shard_count = 1;
     if (opt_.shard_block < 1) opt_.shard_block = 8;
 
@@ -600,8 +601,13 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             table_cap_ = (size_t)tx * ty * 2;
             for (int i = 0; i < kTableRing; i++) {
                 if (table_host_[i]) (void)hipHostFree(table_host_[i]);
-                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, hipHostMallocDefault));
-                if (!table_dev_[i].reserve(table_cap_ * 8)) return false;
+                // Host memory the kernels read in place (no copy in the stream between two dependent launches): non-coherent
+                // = cacheable in the GPU's L2, made visible at kernel boundaries, so a table of a few hundred entries
+                // costs a few dozen PCIe reads per XCD and launch.
+                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, table_zero_copy_ ? hipHostMallocNonCoherent : hipHostMallocDefault));
+                table_ptr_[i] = table_host_[i];
+                if (table_zero_copy_) HIP_OK(hipHostGetDevicePointer((void**)&table_ptr_[i], table_host_[i], 0));
+                else { if (!table_dev_[i].reserve(table_cap_ * 8)) return false; table_ptr_[i] = (uint64_t*)table_dev_[i].p; }
                 table_pending_[i] = false;
             }
         }
@@ -625,8 +631,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             }
             tab[y * tx + x] = ent;
         }
-    HIP_OK(hipMemcpyAsync(table_dev_[ring].p, tab, (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
-    const uint64_t* dtab = (const uint64_t*)table_dev_[ring].p;
+    if (!table_zero_copy_) HIP_OK(hipMemcpyAsync(table_dev_[ring].p, tab, (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
+    const uint64_t* dtab = table_ptr_[ring];
 
     // warp (.cpp:443-452)
     WarpArgs a{};
@@ -813,7 +819,7 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.cx0 = fr.C[i].x0; q.cy0 = fr.C[i].y0; q.cx1 = fr.C[i].x1; q.cy1 = fr.C[i].y1;
         q.tiles_x = fr.tx; q.top_select = top; q.write_next = !top; q.from_warp = (i == 0);
         q.gw_in = i == 0 ? nullptr : in[i].p; q.gw_out = top ? nullptr : out[i + 1].p;
-        q.table = (const uint64_t*)table_dev_[fr.ring].p;
+        q.table = table_ptr_[fr.ring];
         bytes += fr.bytes[i];
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid

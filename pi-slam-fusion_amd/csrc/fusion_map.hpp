@@ -149,6 +149,8 @@ private:
     hipStream_t prof_stream_ = nullptr;
     static constexpr int kUpperStreams = 1;         // streams shared by pyramid levels >= 1
     uint64_t*  table_host_[kTableRing]{};
+    uint64_t*  table_ptr_[kTableRing]{};            // what the kernels dereference: the host table itself (zero copy) or table_dev_
+    bool       table_zero_copy_ = true;
     DevBuf     table_dev_[kTableRing];
     size_t     table_cap_ = 0;
     hipEvent_t table_ev_[kTableRing]{};             // fused = 2/3: last reader of the ring slot done (own stream)

@@ -3,7 +3,7 @@
 a="$1"; b="$2"; n=${3:-3}; shift 3
 for i in $(seq $n); do
   for v in "$a" "$b"; do
-    r=$(env $v python bench.py --no-cpu --preroll-ms 0 "$@" 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['roofline']['avg_launch_us'])")
+    r=$(env $v python bench.py --no-cpu "$@" 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['roofline']['avg_launch_us'])")
     echo "[$v] $r"
   done
 done
