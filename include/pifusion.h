@@ -163,6 +163,39 @@ size_t  pf_tile_bytes(pf_map* m);
 int     pf_tile_export(pf_map* m, int ix, int iy, void* dev_out);
 int     pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in);
 
+/* --- the seam exchange inside the library ---------------------------------
+ * What a reference-side caller (the Map2DHIP subclass of INTEGRATION.md) needs to run draw() and save() when the mosaic is
+ * sharded over the GPUs of a node: one process per GPU, each with its own pf_map created with shard_rank / shard_count,
+ * every keyframe fed to every rank (feed has no collective).  Reference semantics reproduced across ranks: the neighbour
+ * gather of draw(), MultiBandMap2DCPU.cpp:724-741 with Ele::blend :77-146, and the per-level paste + single collapse of
+ * save(), :806-836.  Transport: RCCL (grouped ncclSend/ncclRecv between tile owners over xGMI; librccl is loaded at run
+ * time) or a caller-supplied host-buffer exchange (tests, gloo / MPI launchers).  Collective calls: every rank of the
+ * group must make the same pf_dist_* call.                                                                          */
+typedef struct pf_dist pf_dist;
+/* all-to-all-v over host buffers, indexed by peer rank (own entry: 0 bytes); 1 = ok */
+typedef int (*pf_exchange_fn)(void* user, const void* const* send, const size_t* send_bytes,
+                              void* const* recv, const size_t* recv_bytes, int nranks);
+/* ncclGetUniqueId: 128 bytes, made on one rank and handed to all (by the launcher's own means) */
+int      pf_dist_unique_id(void* out128);
+pf_dist* pf_dist_init_rccl(pf_map* m, const void* unique_id128, int rank, int nranks);
+pf_dist* pf_dist_init_host(pf_map* m, int rank, int nranks, pf_exchange_fn fn, void* user);
+void     pf_dist_destroy(pf_dist* d);
+/* draw() across ranks: every rank blends ITS changed tiles (at most cap) with the edge strips of neighbours that live on
+ * other ranks and clears their Ischanged flags.  One pack launch, one grouped exchange, one batched blend per call.
+ * Returns the number of tiles written to xy / bgr (cap tiles of 256x256x3 each), -1 on failure.                     */
+int      pf_dist_blend_changed(pf_dist* d, int* xy, uint8_t* bgr, int cap);
+/* save() across ranks: every tile travels once to rank 0, which runs the whole-mosaic collapse and (pf_dist_save) writes
+ * the file.  On the other ranks the calls return 1 with rows = cols = 0.                                            */
+int      pf_dist_save(pf_dist* d, const char* filename);
+int      pf_dist_save_to_memory(pf_dist* d, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);
+/* what the last pf_dist_* call moved */
+typedef struct pf_dist_stats {
+    unsigned long long bytes_sent, bytes_received;   /* payload, this rank */
+    unsigned long long strips_sent, strips_received, tiles, peers;
+    double plan_ms, pack_ms, exchange_ms, compute_ms;
+} pf_dist_stats;
+int      pf_dist_last_stats(pf_dist* d, pf_dist_stats* out);
+
 /* --- measurement -------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the map's own stream.  mode 0 = off,
  * 1 = every kernel, 2+k = only kernel k (index in pf_profile_read order); adding n << 8 times every

@@ -33,6 +33,16 @@ class Image(C.Structure):
                 ("step", C.c_size_t)]
 
 
+class DistStats(C.Structure):
+    _fields_ = [("bytes_sent", C.c_ulonglong), ("bytes_received", C.c_ulonglong), ("strips_sent", C.c_ulonglong),
+                ("strips_received", C.c_ulonglong), ("tiles", C.c_ulonglong), ("peers", C.c_ulonglong),
+                ("plan_ms", C.c_double), ("pack_ms", C.c_double), ("exchange_ms", C.c_double), ("compute_ms", C.c_double)]
+
+
+# pf_exchange_fn: all-to-all-v over host buffers (include/pifusion.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                          C.POINTER(C.c_size_t), C.c_int)
+
 _lib = None
 
 
@@ -92,6 +102,14 @@ def lib():
     L.pf_tile_bytes.argtypes = [vp]; L.pf_tile_bytes.restype = C.c_size_t
     L.pf_tile_export.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_tile_import.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.pf_dist_unique_id.argtypes = [vp]
+    L.pf_dist_init_rccl.argtypes = [vp, vp, C.c_int, C.c_int]; L.pf_dist_init_rccl.restype = vp
+    L.pf_dist_init_host.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]; L.pf_dist_init_host.restype = vp
+    L.pf_dist_destroy.argtypes = [vp]; L.pf_dist_destroy.restype = None
+    L.pf_dist_blend_changed.argtypes = [vp, ip, vp, C.c_int]
+    L.pf_dist_save.argtypes = [vp, C.c_char_p]
+    L.pf_dist_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
+    L.pf_dist_last_stats.argtypes = [vp, C.POINTER(DistStats)]
     L.pf_profile_enable.argtypes = [vp, C.c_int]
     L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
     L.pf_profile_reset.argtypes = [vp]

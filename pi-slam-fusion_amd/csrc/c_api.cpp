@@ -1,5 +1,5 @@
 // c_api.cpp -- extern "C" surface of libpifusion.so (include/pifusion.h).
-#include "fusion_map.hpp"
+#include "dist.hpp"
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -116,6 +116,28 @@ int pf_blend_tile_halo(pf_map* m, int ix, int iy, const void* const dev_halo[9],
 size_t pf_tile_bytes(pf_map* m) { return m ? m->impl.tile_bytes() : 0; }
 int pf_tile_export(pf_map* m, int ix, int iy, void* dev_out) { return m && dev_out && m->impl.tile_export(ix, iy, dev_out); }
 int pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in) { return m && dev_in && m->impl.tile_import(ix, iy, dev_in); }
+
+// --- seam exchange (dist.cpp)
+struct pf_dist { pf::DistMap impl; pf_dist(pf::FusionMap* m, pf::Transport* t) : impl(m, t) {} };
+int pf_dist_unique_id(void* out128) { return out128 && pf::rccl_unique_id(out128); }
+pf_dist* pf_dist_init_rccl(pf_map* m, const void* id128, int rank, int nranks)
+{
+    if (!m || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
+    pf::Transport* t = pf::make_rccl_transport(id128, rank, nranks, m->impl.device());
+    return t ? new (std::nothrow) pf_dist(&m->impl, t) : nullptr;
+}
+pf_dist* pf_dist_init_host(pf_map* m, int rank, int nranks, pf_exchange_fn fn, void* user)
+{
+    if (!m || !fn || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
+    pf::Transport* t = pf::make_host_transport(rank, nranks, fn, user);
+    return t ? new (std::nothrow) pf_dist(&m->impl, t) : nullptr;
+}
+void pf_dist_destroy(pf_dist* d) { delete d; }
+int pf_dist_blend_changed(pf_dist* d, int* xy, uint8_t* bgr, int cap) { return (d && xy && bgr && cap >= 0) ? d->impl.blend_changed(xy, bgr, cap) : -1; }
+int pf_dist_save(pf_dist* d, const char* filename) { return d && filename && d->impl.save(filename); }
+int pf_dist_save_to_memory(pf_dist* d, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
+{ return d && rows && cols && tx0 && ty0 && d->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
+int pf_dist_last_stats(pf_dist* d, pf_dist_stats* out) { if (!d || !out) return 0; *out = d->impl.stats(); return 1; }
 
 int pf_profile_enable(pf_map* m, int mode) { if (!m) return 0; m->impl.profile_enable(mode); return 1; }
 int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes)

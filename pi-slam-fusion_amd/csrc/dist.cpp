@@ -1,0 +1,373 @@
+// dist.cpp -- the seam exchange of the tile-sharded mosaic inside the library: what a reference-side caller
+// (the Map2DHIP subclass of INTEGRATION.md) needs to run draw() and save() across the GPUs of a node.
+//
+// feed() has no collective: every rank is fed every keyframe and renders the tiles it owns.  Two steps exchange data:
+//   * draw()  -- Ele::blend's 3x3 neighbour gather (Map2DFusion/MultiBandMap2DCPU.cpp:724-741, :93-117): a changed tile
+//               whose neighbours live on other ranks gets their edge strips (border 1<<(L-i) pixels at level i).  Per call:
+//               ONE pack launch for all strips this rank provides, ONE grouped point-to-point exchange (ncclSend/ncclRecv
+//               to the <= 8 neighbour owners: every xGMI link at once, no ring), ONE batched blend.
+//   * save()  -- the per-level paste of every tile into the mosaic (.cpp:806-836): whole tiles travel once to rank 0, which
+//               runs the single whole-mosaic collapse over its own and the gathered tiles.
+// Both sides derive the exchange plan from the same all-gathered tile lists, so no header travels with the payload.
+//
+// Transport: RCCL (dlopen'ed: librccl is not a link-time dependency) or a caller-supplied host-buffer exchange hook
+// (tests, gloo rehearsals on one GPU, MPI in a reference-side launcher).
+#include "dist.hpp"
+#include <dlfcn.h>
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <map>
+
+namespace pf {
+
+#define HIP_OK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+            return false;                                                                  \
+        }                                                                                  \
+    } while (0)
+
+// ------------------------------------------------------------------ RCCL, resolved at run time
+struct Id128 { char b[128]; };      // ncclUniqueId
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128 /* ncclUniqueId by value */, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static Rccl g_rccl;
+
+static bool load_rccl()
+{
+    if (g_rccl.lib) return true;
+    const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_error("RCCL not found (librccl.so.1)"); return false; }
+#define SYM(field, name) *(void**)&g_rccl.field = dlsym(h, name); if (!g_rccl.field) { set_error("RCCL symbol missing: " name); return false; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.lib = h;
+    return true;
+}
+
+bool rccl_unique_id(void* out128)
+{
+    if (!load_rccl()) return false;
+    const int rc = g_rccl.GetUniqueId(out128);
+    if (rc) { set_error(std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(rc)); return false; }
+    return true;
+}
+
+class RcclTransport : public Transport {
+public:
+    bool init(const void* id128, int r, int n, int device)
+    {
+        rank = r; nranks = n; device_ = device;
+        if (!load_rccl()) return false;
+        Id128 id; std::memcpy(id.b, id128, 128);
+        HIP_OK(hipSetDevice(device));
+        const int rc = g_rccl.CommInitRank(&comm_, n, id, r);
+        if (rc) { set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc)); return false; }
+        return true;
+    }
+    ~RcclTransport() override { if (comm_) g_rccl.CommDestroy(comm_); if (stage_s_) (void)hipFree(stage_s_); if (stage_r_) (void)hipFree(stage_r_); }
+    const char* name() const override { return "rccl"; }
+
+    // grouped point-to-point: every pair with bytes to move gets one send and one recv, issued together
+    bool exchange_dev(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                      const std::vector<size_t>& rb, hipStream_t st) override
+    {
+        int rc = g_rccl.GroupStart();
+        for (int p = 0; p < nranks && !rc; p++) {
+            if (p == rank) continue;
+            if (sb[p]) rc = g_rccl.Send(send[p], sb[p], /* ncclUint8 */ 1, p, comm_, st);
+            if (!rc && rb[p]) rc = g_rccl.Recv(recv[p], rb[p], 1, p, comm_, st);
+        }
+        const int rc2 = g_rccl.GroupEnd();
+        if (rc || rc2) { set_error(std::string("ncclSend/Recv: ") + g_rccl.GetErrorString(rc ? rc : rc2)); return false; }
+        HIP_OK(hipStreamSynchronize(st));
+        return true;
+    }
+    // small control messages travel the same way through device staging
+    bool exchange_host(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                       const std::vector<size_t>& rb, hipStream_t st) override
+    {
+        size_t ts = 0, tr = 0;
+        for (int p = 0; p < nranks; p++) if (p != rank) { ts += sb[p]; tr += rb[p]; }
+        if (!grow(stage_s_, cap_s_, ts) || !grow(stage_r_, cap_r_, tr)) return false;
+        std::vector<const void*> ds(nranks, nullptr); std::vector<void*> dr(nranks, nullptr);
+        size_t os = 0, orr = 0;
+        for (int p = 0; p < nranks; p++) {
+            if (p == rank) continue;
+            ds[p] = stage_s_ + os; dr[p] = stage_r_ + orr;
+            if (sb[p]) HIP_OK(hipMemcpyAsync(stage_s_ + os, send[p], sb[p], hipMemcpyHostToDevice, st));
+            os += sb[p]; orr += rb[p];
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        if (!exchange_dev(ds, sb, dr, rb, st)) return false;
+        orr = 0;
+        for (int p = 0; p < nranks; p++) {
+            if (p == rank) continue;
+            if (rb[p]) HIP_OK(hipMemcpy(recv[p], stage_r_ + orr, rb[p], hipMemcpyDeviceToHost));
+            orr += rb[p];
+        }
+        return true;
+    }
+private:
+    static bool grow(char*& p, size_t& cap, size_t need)
+    {
+        if (need <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void**)&p, need + 4096) != hipSuccess) { set_error("dist: hipMalloc failed"); return false; }
+        cap = need + 4096;
+        return true;
+    }
+    void* comm_ = nullptr;
+    int   device_ = 0;
+    char *stage_s_ = nullptr, *stage_r_ = nullptr;
+    size_t cap_s_ = 0, cap_r_ = 0;
+};
+
+// host-buffer hook: the caller moves bytes between ranks (gloo, MPI, an in-process rendezvous of threads ...)
+class HostTransport : public Transport {
+public:
+    HostTransport(int r, int n, pf_exchange_fn fn, void* user) : fn_(fn), user_(user) { rank = r; nranks = n; }
+    ~HostTransport() override { if (hs_) (void)hipHostFree(hs_); if (hr_) (void)hipHostFree(hr_); }
+    const char* name() const override { return "host"; }
+    bool exchange_host(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                       const std::vector<size_t>& rb, hipStream_t) override
+    {
+        if (!fn_(user_, send.data(), sb.data(), recv.data(), rb.data(), nranks)) { set_error("dist: the exchange hook failed"); return false; }
+        return true;
+    }
+    bool exchange_dev(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                      const std::vector<size_t>& rb, hipStream_t st) override
+    {
+        size_t ts = 0, tr = 0;
+        for (int p = 0; p < nranks; p++) if (p != rank) { ts += sb[p]; tr += rb[p]; }
+        if (!grow(hs_, cs_, ts) || !grow(hr_, cr_, tr)) return false;
+        std::vector<const void*> s(nranks, nullptr); std::vector<void*> r(nranks, nullptr);
+        size_t os = 0, orr = 0;
+        for (int p = 0; p < nranks; p++) {
+            if (p == rank) continue;
+            s[p] = hs_ + os; r[p] = hr_ + orr;
+            if (sb[p]) HIP_OK(hipMemcpyAsync(hs_ + os, send[p], sb[p], hipMemcpyDeviceToHost, st));
+            os += sb[p]; orr += rb[p];
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        if (!exchange_host(s, sb, r, rb, st)) return false;
+        orr = 0;
+        for (int p = 0; p < nranks; p++) {
+            if (p == rank) continue;
+            if (rb[p]) HIP_OK(hipMemcpyAsync(recv[p], hr_ + orr, rb[p], hipMemcpyHostToDevice, st));
+            orr += rb[p];
+        }
+        HIP_OK(hipStreamSynchronize(st));
+        return true;
+    }
+private:
+    static bool grow(char*& p, size_t& cap, size_t need)
+    {
+        if (need <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc((void**)&p, need + 4096, hipHostMallocDefault) != hipSuccess) { set_error("dist: hipHostMalloc failed"); return false; }
+        cap = need + 4096;
+        return true;
+    }
+    pf_exchange_fn fn_; void* user_;
+    char *hs_ = nullptr, *hr_ = nullptr; size_t cs_ = 0, cr_ = 0;
+};
+
+Transport* make_rccl_transport(const void* id128, int rank, int nranks, int device)
+{
+    RcclTransport* t = new RcclTransport();
+    if (!t->init(id128, rank, nranks, device)) { delete t; return nullptr; }
+    return t;
+}
+Transport* make_host_transport(int rank, int nranks, pf_exchange_fn fn, void* user) { return fn ? new HostTransport(rank, nranks, fn, user) : nullptr; }
+
+// ------------------------------------------------------------------ DistMap
+DistMap::DistMap(FusionMap* m, Transport* t) : m_(m), t_(t) {}
+DistMap::~DistMap() { delete t_; send_.release(); recv_.release(); }
+
+// every rank's tile list (coordinates + Ischanged) on every rank: sizes first, then the records
+// (and every rank's cap on the tiles it will blend in this call: the providers must plan with the requester's cap)
+bool DistMap::gather_lists(std::vector<std::vector<FusionMap::TileRec>>& all, std::vector<long long>& caps, long long my_cap)
+{
+    const int n = t_->nranks, me = t_->rank;
+    all.assign(n, {});
+    caps.assign(n, my_cap);
+    m_->list_tiles(all[me]);
+    if (n == 1) return true;
+    hipStream_t st = m_->stream();
+    struct Head { long long count, cap; } mine{ (long long)all[me].size(), my_cap };
+    std::vector<Head> heads(n);
+    std::vector<const void*> s(n, &mine); std::vector<void*> r(n, nullptr);
+    std::vector<size_t> sb(n, sizeof(Head)), rb(n, sizeof(Head));
+    for (int p = 0; p < n; p++) r[p] = &heads[p];
+    sb[me] = rb[me] = 0;
+    if (!t_->exchange_host(s, sb, r, rb, st)) return false;
+    for (int p = 0; p < n; p++) {
+        if (p == me) continue;
+        caps[p] = heads[p].cap;
+        all[p].resize((size_t)heads[p].count);
+        s[p] = all[me].data(); sb[p] = all[me].size() * sizeof(FusionMap::TileRec);
+        r[p] = all[p].data();  rb[p] = all[p].size() * sizeof(FusionMap::TileRec);
+    }
+    return t_->exchange_host(s, sb, r, rb, st);
+}
+
+// draw() across ranks: blend this rank's changed tiles, with the strips of neighbours that live elsewhere
+int DistMap::blend_changed(int* xy, uint8_t* bgr, int cap)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    stats_ = {};
+    if (!m_->use_device()) return -1;
+    const int n = t_->nranks, me = t_->rank;
+    std::vector<std::vector<FusionMap::TileRec>> all;
+    std::vector<long long> caps;
+    if (!gather_lists(all, caps, cap)) return -1;
+    std::map<std::pair<int, int>, int> owner;                 // (ix,iy) -> rank holding it
+    for (int p = 0; p < n; p++) for (auto& t : all[p]) owner[{ t.ix, t.iy }] = p;
+
+    // plan: for rank r's changed tile whose 3x3 neighbourhood exists somewhere, every neighbour on another rank p
+    // contributes one strip set p -> r.  Order: requester's tiles by (iy,ix), neighbours by j = 3*(dy+1)+(dx+1).
+    std::vector<size_t> send_bytes(n, 0), recv_bytes(n, 0);
+    std::vector<std::vector<FusionMap::StripReq>> send_req(n);
+    struct Want { int tile, j, peer; size_t off; };
+    std::vector<Want> wants;
+    std::vector<std::pair<int, int>> mine;                    // this rank's changed tiles, in order, at most cap
+    const bool hq = m_->high_quality();
+    for (int r = 0; r < n; r++) {
+        int taken = 0;
+        for (auto& t : all[r]) {
+            if (!t.changed) continue;
+            if (taken >= caps[r]) break;                      // rank r blends at most its own cap tiles in this call
+            if (r == me) mine.push_back({ t.ix, t.iy });
+            taken++;
+            if (!hq) continue;
+            bool full = true;
+            for (int j = 0; j < 9 && full; j++) full = owner.count({ t.ix + j % 3 - 1, t.iy + j / 3 - 1 }) != 0;
+            if (!full) continue;                              // blends alone (.cpp:134-145): no strips
+            for (int j = 0; j < 9; j++) {
+                if (j == 4) continue;
+                const int dx = j % 3 - 1, dy = j / 3 - 1, p = owner[{ t.ix + dx, t.iy + dy }];
+                if (p == r) continue;
+                const size_t nb = m_->halo_bytes_for(dx, dy);
+                if (p == me) { send_req[r].push_back({ t.ix + dx, t.iy + dy, dx, dy, send_bytes[r] }); send_bytes[r] += nb; }
+                if (r == me) { wants.push_back({ (int)mine.size() - 1, j, p, recv_bytes[p] }); recv_bytes[p] += nb; }
+            }
+        }
+    }
+    // one send buffer and one receive buffer, peers back to back
+    std::vector<size_t> soff(n, 0), roff(n, 0);
+    size_t ts = 0, tr = 0;
+    for (int p = 0; p < n; p++) { soff[p] = ts; ts += (send_bytes[p] + 255) / 256 * 256; roff[p] = tr; tr += (recv_bytes[p] + 255) / 256 * 256; }
+    if (!send_.reserve(ts + 256) || !recv_.reserve(tr + 256)) return -1;
+    std::vector<FusionMap::StripReq> reqs;
+    for (int p = 0; p < n; p++) for (auto q : send_req[p]) { q.out_off += soff[p]; reqs.push_back(q); }
+    const auto t_pack = std::chrono::steady_clock::now();
+    if (!m_->pack_strips(reqs, send_.p)) return -1;           // ONE launch, ONE sync
+    const auto t_xchg = std::chrono::steady_clock::now();
+    if (n > 1) {
+        std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
+        for (int p = 0; p < n; p++) { s[p] = (char*)send_.p + soff[p]; r[p] = (char*)recv_.p + roff[p]; }
+        std::vector<size_t> sb = send_bytes, rb = recv_bytes;
+        sb[me] = rb[me] = 0;
+        if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return -1;      // returns with the stream drained: the bytes have landed
+    }
+    const auto t_blend = std::chrono::steady_clock::now();
+    std::vector<const void*> halo9(mine.size() * 9, nullptr);
+    for (auto& w : wants) halo9[(size_t)w.tile * 9 + w.j] = (char*)recv_.p + roff[w.peer] + w.off;
+    if (!mine.empty() && !m_->blend_tiles(mine, halo9.data(), bgr)) return -1;
+    for (size_t i = 0; i < mine.size(); i++) { xy[2 * i] = mine[i].first; xy[2 * i + 1] = mine[i].second; }
+    const auto t_end = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    for (int p = 0; p < n; p++) if (p != me) { stats_.bytes_sent += send_bytes[p]; stats_.bytes_received += recv_bytes[p]; stats_.peers += (send_bytes[p] || recv_bytes[p]) ? 1 : 0; }
+    stats_.strips_sent = reqs.size(); stats_.strips_received = wants.size();
+    stats_.plan_ms = ms(t_begin, t_pack); stats_.pack_ms = ms(t_pack, t_xchg); stats_.exchange_ms = ms(t_xchg, t_blend); stats_.compute_ms = ms(t_blend, t_end);
+    stats_.tiles = mine.size();
+    return (int)mine.size();
+}
+
+// save() across ranks: tiles travel once to rank 0, which collapses the whole mosaic (.cpp:779-847).  On the other ranks the
+// call returns true with rows = cols = 0 (they hold no picture).
+bool DistMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
+{
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!m_->use_device()) return false;
+    const int n = t_->nranks, me = t_->rank;
+    if (n == 1) return m_->save_to_memory(bgr, rows, cols, tx0, ty0);
+    std::vector<std::vector<FusionMap::TileRec>> all;
+    std::vector<long long> caps;
+    if (!gather_lists(all, caps, 0)) return false;
+    const size_t nb = m_->tile_bytes();
+    // query (bgr == nullptr): the extent is known from the lists alone
+    if (!bgr) {
+        int mnx = 1 << 30, mny = 1 << 30, mxx = -(1 << 30), mxy = -(1 << 30), cnt = 0;
+        for (auto& l : all) for (auto& t : l) { cnt++; mnx = std::min(mnx, t.ix); mny = std::min(mny, t.iy); mxx = std::max(mxx, t.ix); mxy = std::max(mxy, t.iy); }
+        if (!cnt) return false;
+        if (me == 0) { *rows = (mxy + 1 - mny) * kElePixels; *cols = (mxx + 1 - mnx) * kElePixels; *tx0 = mnx; *ty0 = mny; }
+        else { *rows = *cols = 0; *tx0 = *ty0 = 0; }
+        return true;
+    }
+    std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
+    std::vector<size_t> sb(n, 0), rb(n, 0);
+    stats_ = {};
+    if (me != 0) {
+        std::vector<std::pair<int, int>> mine;
+        for (auto& t : all[me]) mine.push_back({ t.ix, t.iy });
+        if (!send_.reserve(nb * mine.size() + 256)) return false;
+        if (!m_->export_tiles(mine, send_.p)) return false;
+        s[0] = send_.p; sb[0] = nb * mine.size();
+        if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return false;
+        stats_.bytes_sent = sb[0]; stats_.tiles = mine.size();
+        *rows = *cols = 0; *tx0 = *ty0 = 0;
+        stats_.exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return true;
+    }
+    size_t total = 0;
+    std::vector<size_t> off(n, 0);
+    for (int p = 1; p < n; p++) { off[p] = total; total += nb * all[p].size(); }
+    if (!recv_.reserve(total + 256)) return false;
+    for (int p = 1; p < n; p++) { r[p] = (char*)recv_.p + off[p]; rb[p] = nb * all[p].size(); }
+    if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return false;
+    const auto t_x = std::chrono::steady_clock::now();
+    std::vector<FusionMap::ForeignTile> foreign;
+    for (int p = 1; p < n; p++)
+        for (size_t k = 0; k < all[p].size(); k++) foreign.push_back({ all[p][k].ix, all[p][k].iy, (char*)recv_.p + off[p] + k * nb });
+    const bool ok = m_->save_to_memory(bgr, rows, cols, tx0, ty0, &foreign);
+    stats_.bytes_received = total; stats_.tiles = foreign.size();
+    stats_.exchange_ms = std::chrono::duration<double, std::milli>(t_x - t_begin).count();
+    stats_.compute_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_x).count();
+    return ok;
+}
+
+bool DistMap::save(const char* filename)
+{
+    int rows = 0, cols = 0, tx0 = 0, ty0 = 0;
+    if (!save_to_memory(nullptr, &rows, &cols, &tx0, &ty0)) return false;
+    std::vector<uint8_t> img((size_t)rows * cols * 3 + 1);
+    if (!save_to_memory(img.data(), &rows, &cols, &tx0, &ty0)) return false;
+    if (t_->rank != 0) return true;
+    if (!write_image_file(filename, img.data(), rows, cols)) return false;
+    std::printf("Resolution:[%d %d]\n", cols, rows);
+    return true;
+}
+
+}  // namespace pf

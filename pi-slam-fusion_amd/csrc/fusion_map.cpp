@@ -943,70 +943,143 @@ bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
     return true;
 }
 
+// ------------------------------------------------------- seam exchange support (dist.cpp)
+void FusionMap::list_tiles(std::vector<TileRec>& out)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    out.clear();
+    store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) out.push_back({ ix, iy, t.changed ? 1 : 0 }); });
+    std::sort(out.begin(), out.end(), [](const TileRec& a, const TileRec& b) { return a.iy != b.iy ? a.iy < b.iy : a.ix < b.ix; });
+}
+
+// every strip set of one exchange: one descriptor upload, one launch, no sync (the caller orders its transport after stream_)
+bool FusionMap::pack_strips(const std::vector<StripReq>& reqs, void* dev_out)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    if (reqs.empty()) return true;
+    if (!flush_pipeline()) return false;
+    std::vector<StripDesc> d(reqs.size());
+    for (size_t i = 0; i < reqs.size(); i++) {
+        Tile* t = store_.find(reqs[i].ix, reqs[i].iy);
+        if (!t || t->fresh) { set_error("pack_strips: tile not held by this rank"); return false; }
+        d[i] = { t->base, reqs[i].dx, reqs[i].dy, reqs[i].out_off };
+    }
+    if (!strip_desc_.reserve(d.size() * sizeof(StripDesc))) return false;
+    HIP_OK(hipMemcpyAsync(strip_desc_.p, d.data(), d.size() * sizeof(StripDesc), hipMemcpyHostToDevice, stream_));
+    launch_halo_pack_batch(stream_, lay_, (const StripDesc*)strip_desc_.p, (int)d.size(), dev_out);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(stream_));       // d (pageable) is read by the async copy: one sync per exchange, not per strip
+    return true;
+}
+
+// whole tiles (pyramids + weights) of this rank, back to back in dev_out, for save()'s gather
+bool FusionMap::export_tiles(const std::vector<std::pair<int, int>>& tiles, void* dev_out)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device()) return false;
+    if (!flush_pipeline()) return false;
+    for (size_t i = 0; i < tiles.size(); i++) {
+        Tile* t = store_.find(tiles[i].first, tiles[i].second);
+        if (!t || t->fresh) { set_error("export_tiles: tile not held by this rank"); return false; }
+        HIP_OK(hipMemcpyAsync((char*)dev_out + i * lay_.slot_bytes, t->base, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
+    }
+    HIP_OK(hipStreamSynchronize(stream_));
+    return true;
+}
+
+// the changed tiles among `tiles` blended with remote strips; clears their Ischanged flags (draw(), .cpp:705-742)
+bool FusionMap::blend_tiles(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, uint8_t* bgr)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device() || single_band_) return false;
+    if (!blend_batch(tiles, halo9, nullptr, bgr)) return false;
+    for (auto& t : tiles) { Tile* q = store_.find(t.first, t.second); if (q) q->changed = false; }
+    return true;
+}
+
 // ------------------------------------------------------------------ blend
-// Ele::blend (.cpp:77-146) for a batch of tiles.  halo (9 device pointers or
-// nullptr) substitutes packed strip sets for neighbours held by other shards;
-// it applies to single-tile calls only.
-bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const void* const* halo, void* raw_host, uint8_t* bgr_host)
+// Ele::blend (.cpp:77-146) for a list of tiles.  halo9 (nullptr, or 9 device pointers per tile) substitutes packed strip
+// sets for neighbours held by other shards.  Results land in tile order; the tiles are processed in chunks whose pixels
+// come back in ONE device-to-host copy each.
+bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host)
 {
     const int nl = band_num_ + 1, L = band_num_;
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     const size_t tile_px = (size_t)kElePixels * kElePixels;
-    // group tiles by mode: full 3x3 available (border = 1<<(nl-1-i)) or self (border 0)
-    for (int mode = 0; mode < 2; mode++) {
-        std::vector<BlendSrc> srcs;
-        std::vector<int> idx;
-        for (size_t t = 0; t < tiles.size(); t++) {
-            Tile* self = store_.find(tiles[t].first, tiles[t].second);
-            if (!self || self->fresh) continue;
-            BlendSrc nb[9]; bool all = opt_.high_quality_show != 0;
-            for (int dy = -1; dy <= 1 && all; dy++)
-                for (int dx = -1; dx <= 1; dx++) {
-                    const int j = 3 * (dy + 1) + dx + 1;
-                    Tile* n = store_.find(tiles[t].first + dx, tiles[t].second + dy);
-                    if (n && !n->fresh) nb[j] = { n->base, 0 };
-                    else if (halo && halo[j]) nb[j] = { halo[j], 1 };
-                    else { all = false; break; }
-                }
-            if ((all ? 0 : 1) != mode) continue;
-            if (!all) { for (auto& b : nb) b = { nullptr, 0 }; nb[4] = { self->base, 0 }; }
-            srcs.insert(srcs.end(), nb, nb + 9);
-            idx.push_back((int)t);
-        }
-        const int batch = (int)idx.size();
-        if (!batch) continue;
-        const int b0 = mode == 0 ? (1 << (nl - 1)) : 0;
-        if (!blend_src_.reserve(srcs.size() * sizeof(BlendSrc))) return false;
-        HIP_OK(hipMemcpyAsync(blend_src_.p, srcs.data(), srcs.size() * sizeof(BlendSrc), hipMemcpyHostToDevice, stream_));
-        size_t stride[kMaxLevels];
-        for (int i = 0; i < nl; i++) {
-            const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
-            stride[i] = (((size_t)side * side * px + 255) / 256) * 256;
-            if (!blend_lv_[i].reserve(stride[i] * batch)) return false;
-        }
-        if (raw_host && !blend_out_raw_.reserve(tile_px * px * batch)) return false;
-        if (bgr_host && !blend_out_bgr_.reserve(tile_px * 3 * batch)) return false;
-        const BlendSrc* dsrc = (const BlendSrc*)blend_src_.p;
-        for (int i = 0; i < nl; i++) {
-            const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
-            prof_begin(K_BLEND_GATHER, (double)side * side * px * 2 * batch);
-            launch_blend_gather(stream_, lay_, i, b, dsrc, blend_lv_[i].p, stride[i], batch);
+    constexpr size_t kChunk = 128;
+    if (!flush_pipeline()) return false;          // the upper levels of the last frames are still pending: run them first (stream order)
+    for (size_t c0 = 0; c0 < tiles.size(); c0 += kChunk) {
+        const size_t cn = std::min(kChunk, tiles.size() - c0);
+        if (raw_host && !blend_out_raw_.reserve(tile_px * px * cn)) return false;
+        if (bgr_host && !blend_out_bgr_.reserve(tile_px * 3 * cn)) return false;
+        std::vector<char> present(cn, 0);
+        // group the chunk's tiles by mode: full 3x3 available (border = 1<<(nl-1-i)) or self (border 0)
+        for (int mode = 0; mode < 2; mode++) {
+            std::vector<BlendSrc> srcs;
+            std::vector<int> idx;
+            for (size_t t = c0; t < c0 + cn; t++) {
+                Tile* self = store_.find(tiles[t].first, tiles[t].second);
+                if (!self || self->fresh) continue;
+                const void* const* halo = halo9 ? halo9 + 9 * t : nullptr;
+                BlendSrc nb[9]; bool all = opt_.high_quality_show != 0;
+                for (int dy = -1; dy <= 1 && all; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int j = 3 * (dy + 1) + dx + 1;
+                        Tile* n = store_.find(tiles[t].first + dx, tiles[t].second + dy);
+                        if (n && !n->fresh) nb[j] = { n->base, 0 };
+                        else if (halo && halo[j]) nb[j] = { halo[j], 1 };
+                        else { all = false; break; }
+                    }
+                if ((all ? 0 : 1) != mode) continue;
+                if (!all) { for (auto& q : nb) q = { nullptr, 0 }; nb[4] = { self->base, 0 }; }
+                srcs.insert(srcs.end(), nb, nb + 9);
+                idx.push_back((int)(t - c0));
+                present[t - c0] = 1;
+            }
+            const int batch = (int)idx.size();
+            if (!batch) continue;
+            const int b0 = mode == 0 ? (1 << (nl - 1)) : 0;
+            const size_t src_bytes = srcs.size() * sizeof(BlendSrc), idx_off = (src_bytes + 255) / 256 * 256;
+            if (!blend_src_.reserve(idx_off + idx.size() * sizeof(int))) return false;
+            HIP_OK(hipMemcpyAsync(blend_src_.p, srcs.data(), src_bytes, hipMemcpyHostToDevice, stream_));
+            HIP_OK(hipMemcpyAsync((char*)blend_src_.p + idx_off, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+            size_t stride[kMaxLevels];
+            for (int i = 0; i < nl; i++) {
+                const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
+                stride[i] = (((size_t)side * side * px + 255) / 256) * 256;
+                if (!blend_lv_[i].reserve(stride[i] * batch)) return false;
+            }
+            const BlendSrc* dsrc = (const BlendSrc*)blend_src_.p;
+            for (int i = 0; i < nl; i++) {
+                const int b = mode == 0 ? (1 << (nl - 1 - i)) : 0, side = (kElePixels >> i) + 2 * b;
+                prof_begin(K_BLEND_GATHER, (double)side * side * px * 2 * batch);
+                launch_blend_gather(stream_, lay_, i, b, dsrc, blend_lv_[i].p, stride[i], batch);
+                prof_end();
+            }
+            for (int i = L; i > 0; i--) {
+                const int b = mode == 0 ? (1 << (nl - i)) : 0, side = (kElePixels >> (i - 1)) + 2 * b;
+                prof_begin(K_COLLAPSE, (double)side * side * px * 2.25 * batch);
+                launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, stride[i - 1], blend_lv_[i].p, stride[i], side, side, batch);
+                prof_end();
+            }
+            prof_begin(K_BLEND_FINISH, (double)tile_px * (px + 4 + 3) * batch);
+            launch_blend_finish(stream_, lay_, blend_lv_[0].p, stride[0], b0, dsrc, raw_host ? blend_out_raw_.p : nullptr,
+                                bgr_host ? (uint8_t*)blend_out_bgr_.p : nullptr, batch, (const int*)((char*)blend_src_.p + idx_off));
             prof_end();
+            HIP_OK(hipStreamSynchronize(stream_));              // srcs / idx are reused by the other mode
         }
-        for (int i = L; i > 0; i--) {
-            const int b = mode == 0 ? (1 << (nl - i)) : 0, side = (kElePixels >> (i - 1)) + 2 * b;
-            prof_begin(K_COLLAPSE, (double)side * side * px * 2.25 * batch);
-            launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, stride[i - 1], blend_lv_[i].p, stride[i], side, side, batch);
-            prof_end();
-        }
-        prof_begin(K_BLEND_FINISH, (double)tile_px * (px + 4 + 3) * batch);
-        launch_blend_finish(stream_, lay_, blend_lv_[0].p, stride[0], b0, dsrc, raw_host ? blend_out_raw_.p : nullptr,
-                            bgr_host ? (uint8_t*)blend_out_bgr_.p : nullptr, batch);
-        prof_end();
-        HIP_OK(sync_all());
-        for (int k = 0; k < batch; k++) {
-            if (raw_host) HIP_OK(hipMemcpy((char*)raw_host + (size_t)idx[k] * tile_px * px, (char*)blend_out_raw_.p + (size_t)k * tile_px * px, tile_px * px, hipMemcpyDeviceToHost));
-            if (bgr_host) HIP_OK(hipMemcpy(bgr_host + (size_t)idx[k] * tile_px * 3, (char*)blend_out_bgr_.p + (size_t)k * tile_px * 3, tile_px * 3, hipMemcpyDeviceToHost));
+        // one copy per chunk (tiles that do not exist keep the caller's bytes: copy the runs that do)
+        size_t r0 = 0;
+        while (r0 < cn) {
+            while (r0 < cn && !present[r0]) r0++;
+            size_t r1 = r0;
+            while (r1 < cn && present[r1]) r1++;
+            if (r1 > r0) {
+                if (raw_host) HIP_OK(hipMemcpy((char*)raw_host + (c0 + r0) * tile_px * px, (char*)blend_out_raw_.p + r0 * tile_px * px, (r1 - r0) * tile_px * px, hipMemcpyDeviceToHost));
+                if (bgr_host) HIP_OK(hipMemcpy(bgr_host + (c0 + r0) * tile_px * 3, (char*)blend_out_bgr_.p + r0 * tile_px * 3, (r1 - r0) * tile_px * 3, hipMemcpyDeviceToHost));
+            }
+            r0 = r1;
         }
     }
     return true;
@@ -1056,10 +1129,7 @@ int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
         }
         return (int)tiles.size();
     }
-    for (size_t o = 0; o < tiles.size(); o += 64) {
-        std::vector<std::pair<int, int>> part(tiles.begin() + o, tiles.begin() + std::min(tiles.size(), o + 64));
-        if (!blend_batch(part, nullptr, nullptr, bgr + o * tile_px)) return 0;
-    }
+    if (sync_all() != hipSuccess || !blend_batch(tiles, nullptr, nullptr, bgr)) return 0;
     for (size_t i = 0; i < tiles.size(); i++) {
         xy[2 * i] = tiles[i].first; xy[2 * i + 1] = tiles[i].second;
         store_.find(tiles[i].first, tiles[i].second)->changed = false;
@@ -1070,7 +1140,7 @@ int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
 // ------------------------------------------------------------------- save
 // MultiBandMap2DCPU::save (.cpp:779-847): paste all tiles per level, collapse
 // the whole mosaic once, 8U, background where level-0 weight is 0.
-bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
+bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0, const std::vector<ForeignTile>* foreign)
 {
     std::lock_guard<std::mutex> l(mu_);
     if (!init_ok_ || !valid_ || !set_device()) return false;
@@ -1080,6 +1150,8 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
         if (t.fresh) return;
         cnt++; mnx = std::min(mnx, ix); mny = std::min(mny, iy); mxx = std::max(mxx, ix); mxy = std::max(mxy, iy);
     });
+    // tiles of other ranks gathered for this save (dist.cpp): they take part in the mosaic without entering the store
+    if (foreign) for (auto& f : *foreign) { cnt++; mnx = std::min(mnx, f.ix); mny = std::min(mny, f.iy); mxx = std::max(mxx, f.ix); mxy = std::max(mxy, f.iy); }
     if (!cnt) return false;
     const int wx = mxx + 1 - mnx, wy = mxy + 1 - mny;
     *rows = wy * kElePixels; *cols = wx * kElePixels; *tx0 = mnx; *ty0 = mny;
@@ -1104,6 +1176,7 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     std::vector<uint64_t> tab((size_t)wx * wy, 0);
     store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) tab[(size_t)(iy - mny) * wx + (ix - mnx)] = (uint64_t)(uintptr_t)t.base; });
+    if (foreign) for (auto& f : *foreign) tab[(size_t)(f.iy - mny) * wx + (f.ix - mnx)] = (uint64_t)(uintptr_t)f.dev;
     HIP_OK(sync_all());
     if (!mosaic_table_.reserve(tab.size() * 8)) return false;
     HIP_OK(hipMemcpy(mosaic_table_.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));

@@ -83,7 +83,20 @@ public:
     long read_back_last_frame(void* out, size_t cap);
     bool sync();
     bool save(const char* filename);
-    bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
+    struct ForeignTile { int ix, iy; const void* dev; };          // a tile slot image held outside the store (gathered for save)
+    bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0, const std::vector<ForeignTile>* foreign = nullptr);
+
+    // seam exchange support (dist.cpp)
+    struct TileRec  { int ix, iy, changed; };
+    struct StripReq { int ix, iy, dx, dy; size_t out_off; };      // tile (ix,iy) of THIS rank hands its edge facing (-dx,-dy)... see pf_halo_pack
+    void list_tiles(std::vector<TileRec>& out);
+    bool pack_strips(const std::vector<StripReq>& reqs, void* dev_out);
+    bool export_tiles(const std::vector<std::pair<int, int>>& tiles, void* dev_out);
+    bool blend_tiles(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, uint8_t* bgr);
+    hipStream_t stream() const { return stream_; }
+    int  device() const { return device_; }
+    bool use_device() { return set_device(); }
+    bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
     int  num_levels() const { return band_num_ + 1; }
     int  pyramid_type() const { return single_band_ ? PF_8UC4 : (lay_.f32 ? PF_32FC3 : PF_16SC3); }
@@ -113,7 +126,7 @@ private:
     void worker();                                                 // .cpp:619-635
     int  acquire_slot(size_t bytes);
     bool upload(const pf_image* img, int slot);
-    bool blend_batch(const std::vector<std::pair<int,int>>& tiles, const void* const* halo, void* raw_host, uint8_t* bgr_host);
+    bool blend_batch(const std::vector<std::pair<int,int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host);
     void prof_begin(int id, double bytes, hipStream_t st = nullptr);
     hipError_t sync_all();
     void prof_end();
@@ -179,7 +192,7 @@ private:
     bool flush_pipeline();
 
     // blend / save scratch
-    DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_;
+    DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_, strip_desc_;
 
     // frame staging + feed queue
     std::vector<FrameSlot> slots_;

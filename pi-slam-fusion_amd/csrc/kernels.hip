@@ -1310,15 +1310,17 @@ __device__ __forceinline__ uint8_t sat_uchar(int v) { return (uint8_t)(v < 0 ? 0
 // crop the centre 256^2, zero where weights[0]==0 (.cpp:121-126,144), optional 8U view (.cpp:156)
 template <bool F32>
 __global__ __launch_bounds__(256) void k_blend_finish(TileLayout lay, const char* __restrict__ lvl0, size_t stride, int border,
-                                                       const BlendSrc* __restrict__ srcs, char* __restrict__ raw, uint8_t* __restrict__ bgr)
+                                                       const BlendSrc* __restrict__ srcs, char* __restrict__ raw, uint8_t* __restrict__ bgr,
+                                                       const int* __restrict__ out_idx)
 {
     using T = typename Pix<F32>::T;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    const int zo = out_idx ? out_idx[z] : z;                 // where this tile goes in the output (batches are cut by blend mode)
     const int side = kElePixels + 2 * border;
     const T* s = reinterpret_cast<const T*>(lvl0 + z * stride) + ((long)(y + border) * side + x + border) * 3;
     const float* w0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(srcs[z * 9 + 4].base) + lay.w_off[0]);
     const bool zero = w0[y * kElePixels + x] == 0.f;
-    const long o = ((long)z * kElePixels * kElePixels + y * kElePixels + x) * 3;
+    const long o = ((long)zo * kElePixels * kElePixels + y * kElePixels + x) * 3;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const T v = zero ? (T)0 : s[k];
@@ -1331,11 +1333,11 @@ __global__ __launch_bounds__(256) void k_blend_finish(TileLayout lay, const char
 }
 
 void launch_blend_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, size_t stride_bytes, int border,
-                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch)
+                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch, const int* out_idx)
 {
     dim3 grid(kElePixels / 64, kElePixels / 4, batch), block(256);
-    if (lay.f32) hipLaunchKernelGGL(k_blend_finish<true>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out);
-    else         hipLaunchKernelGGL(k_blend_finish<false>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out);
+    if (lay.f32) hipLaunchKernelGGL(k_blend_finish<true>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out, out_idx);
+    else         hipLaunchKernelGGL(k_blend_finish<false>, grid, block, 0, s, lay, (const char*)lvl0, stride_bytes, border, srcs, (char*)raw_out, bgr_out, out_idx);
 }
 
 // ------------------------------------------------------------------- save
@@ -1422,6 +1424,38 @@ void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, in
     dim3 grid(32, lay.nlev), block(256);
     if (lay.f32) hipLaunchKernelGGL(k_halo_pack<true>, grid, block, 0, s, lay, (const char*)slot, dx, dy, (char*)out);
     else         hipLaunchKernelGGL(k_halo_pack<false>, grid, block, 0, s, lay, (const char*)slot, dx, dy, (char*)out);
+}
+
+// every strip set of an exchange in one launch: blockIdx.z = strip set, blockIdx.y = level
+template <bool F32>
+__global__ __launch_bounds__(256) void k_halo_pack_batch(TileLayout lay, const StripDesc* __restrict__ descs, char* __restrict__ out)
+{
+    using T = typename Pix<F32>::T;
+    const StripDesc d = descs[blockIdx.z];
+    const int level = blockIdx.y, dx = d.dx, dy = d.dy;
+    const int ts = kElePixels >> level, b = 1 << (lay.nlev - 1 - level);
+    int w, h; strip_dims(lay.nlev, level, dx, dy, w, h);
+    long off = 0;
+    for (int i = 0; i < level; i++) { int ww, hh; strip_dims(lay.nlev, i, dx, dy, ww, hh); off += (long)ww * hh; }
+    const int sx0 = dx < 0 ? ts - b : 0, sy0 = dy < 0 ? ts - b : 0;
+    const T* s = reinterpret_cast<const T*>(reinterpret_cast<const char*>(d.slot) + lay.lap_off[level]);
+    T* o = reinterpret_cast<T*>(out + d.out_off) + off * 3;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int ly = i / w, lx = i - ly * w;
+        const long sp = ((long)(sy0 + ly) * ts + sx0 + lx) * 3;
+        o[(long)i * 3] = s[sp]; o[(long)i * 3 + 1] = s[sp + 1]; o[(long)i * 3 + 2] = s[sp + 2];
+    }
+}
+
+void launch_halo_pack_batch(hipStream_t s, const TileLayout& lay, const StripDesc* descs_dev, int n, void* out)
+{
+    if (n <= 0) return;
+    for (int z0 = 0; z0 < n; z0 += 65535) {                    // gridDim.z limit
+        const int nz = n - z0 < 65535 ? n - z0 : 65535;
+        dim3 grid(8, lay.nlev, nz), block(256);
+        if (lay.f32) hipLaunchKernelGGL(k_halo_pack_batch<true>, grid, block, 0, s, lay, descs_dev + z0, (char*)out);
+        else         hipLaunchKernelGGL(k_halo_pack_batch<false>, grid, block, 0, s, lay, descs_dev + z0, (char*)out);
+    }
 }
 
 // ------------------------------------------------------------------ misc

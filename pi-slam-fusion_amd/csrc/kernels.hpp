@@ -93,7 +93,7 @@ void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int bo
 void launch_collapse(hipStream_t s, bool f32, void* dst, size_t dst_stride_bytes, const void* src,
                      size_t src_stride_bytes, int rows, int cols, int batch);
 void launch_blend_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, size_t stride_bytes, int border,
-                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch);
+                         const BlendSrc* srcs, void* raw_out, uint8_t* bgr_out, int batch, const int* out_idx = nullptr);
 
 // save(): paste tiles of a dense (wx x wy) table into one mosaic level, then collapse, then finish
 void launch_mosaic_gather(hipStream_t s, const TileLayout& lay, int level, const uint64_t* table, int wx, int wy, void* dst);
@@ -103,6 +103,9 @@ void launch_save_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, 
 // halo strip pack (multi-GPU blend): writes the strip set a neighbour at (dx,dy) needs
 size_t halo_bytes(const TileLayout& lay, int dx, int dy);
 void launch_halo_pack(hipStream_t s, const TileLayout& lay, const void* slot, int dx, int dy, void* out);
+// all strip sets of a seam exchange in one launch (descs in device memory; out_off = byte offset of a set in `out`)
+struct StripDesc { const void* slot; int dx, dy; size_t out_off; };
+void launch_halo_pack_batch(hipStream_t s, const TileLayout& lay, const StripDesc* descs_dev, int n, void* out);
 
 // Map2DCPU semantics (single_band.hip): weight byte plane, BGRA warp + select into 256x256x4 tiles
 void launch_weight8(hipStream_t s, uint8_t* w, int rows, int cols, int weight_type);

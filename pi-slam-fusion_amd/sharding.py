@@ -9,15 +9,113 @@ recomputes the pyramid halo from the source frame.  The only exchange steps are
     moved with ONE all_to_all (point-to-point traffic over xGMI, all links at once);
   * save (.cpp:779-847): whole tiles are gathered to rank 0, which runs the mosaic collapse.
 
-The transport is torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU); the engine
-behind it is anything with the small interface of `GpuEngine` below -- the HIP library on a
-GPU box, the oracle-backed stand-in of tests/test_sharding_gloo.py on CPU.
+On a GPU the exchange lives in the library (csrc/dist.cpp, C ABI pf_dist_*: one pack launch, one grouped
+ncclSend/ncclRecv exchange, one batched blend per call); `DistMap` below is its thin caller.  The functions
+after it are the same plan in Python over torch.distributed and an engine interface: the CPU model of the
+exchange that tests/test_sharding_gloo.py runs with an oracle-backed engine (no GPU there).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 NEIGHBOURS = [(dx, dy) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]      # index j = 3*(dy+1)+(dx+1)
+
+
+def _pkg():
+    import sys
+    return sys.modules[__name__.rsplit(".", 1)[0]]
+
+
+def torch_exchange(group=None):
+    """pf_exchange_fn over torch.distributed point-to-point (works with gloo): the host-buffer transport of the
+    library for rehearsals where RCCL cannot be used (several ranks sharing one GPU)."""
+    def fn(user, send, send_bytes, recv, recv_bytes, n):
+        try:
+            me = dist.get_rank(group)
+            ops, keep = [], []
+            for p in range(n):
+                if p == me:
+                    continue
+                if send_bytes[p]:
+                    t = torch.frombuffer((C.c_char * send_bytes[p]).from_address(send[p]), dtype=torch.uint8)
+                    keep.append(t); ops.append(dist.P2POp(dist.isend, t, p, group))
+                if recv_bytes[p]:
+                    t = torch.frombuffer((C.c_char * recv_bytes[p]).from_address(recv[p]), dtype=torch.uint8)
+                    keep.append(t); ops.append(dist.P2POp(dist.irecv, t, p, group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return 1
+        except Exception as e:                              # never let an exception cross the C boundary
+            print("torch_exchange failed:", e)
+            return 0
+    return fn
+
+
+class DistMap:
+    """Thin caller of the library's seam exchange (pf_dist_*).  backend "nccl": RCCL, the unique id made on rank 0 and
+    broadcast through torch.distributed; anything else: the host-buffer hook over `exchange` (default: torch p2p)."""
+
+    def __init__(self, m, rank, nranks, backend="nccl", exchange=None, group=None):
+        pf = _pkg()
+        L = pf.lib()
+        self.m, self.rank, self.nranks, self._fn = m, rank, nranks, None
+        if backend == "nccl":
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                assert L.pf_dist_unique_id(uid.data_ptr()), L.pf_last_error().decode()
+            if nranks > 1:
+                dev = uid.cuda() if dist.get_backend(group) == "nccl" else uid
+                dist.broadcast(dev, 0, group=group)
+                uid = dev.cpu()
+            self._h = L.pf_dist_init_rccl(m._h, uid.data_ptr(), rank, nranks)
+        else:
+            self._fn = pf.EXCHANGE_FN(exchange or torch_exchange(group))
+            self._h = L.pf_dist_init_host(m._h, rank, nranks, self._fn, None)
+        if not self._h:
+            raise RuntimeError("pf_dist_init failed: %s" % L.pf_last_error().decode())
+
+    def close(self):
+        if self._h:
+            _pkg().lib().pf_dist_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def blend_changed(self, cap=None):
+        """draw() across ranks: this rank's changed tiles, blended with remote neighbour strips -> (coords, pixels)"""
+        pf = _pkg()
+        cap = max(1, len(self.m.tiles())) if cap is None else cap
+        xy = (C.c_int * (2 * max(cap, 1)))()
+        out = np.empty((max(cap, 1), pf.ELE_PIXELS, pf.ELE_PIXELS, 3), np.uint8)
+        n = pf.lib().pf_dist_blend_changed(self._h, xy, out.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("pf_dist_blend_changed failed: %s" % pf.lib().pf_last_error().decode())
+        return [(xy[2 * i], xy[2 * i + 1]) for i in range(n)], out[:n]
+
+    def save_to_memory(self):
+        """save() across ranks: rank 0 gets (mosaic, origin tile); the other ranks get None"""
+        L = _pkg().lib()
+        r, c, x0, y0 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if not L.pf_dist_save_to_memory(self._h, None, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
+            raise RuntimeError("pf_dist_save_to_memory failed: %s" % L.pf_last_error().decode())
+        out = np.empty((max(r.value, 1), max(c.value, 1), 3), np.uint8)
+        if not L.pf_dist_save_to_memory(self._h, out.ctypes.data, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
+            raise RuntimeError("pf_dist_save_to_memory failed: %s" % L.pf_last_error().decode())
+        return (out, (x0.value, y0.value)) if self.rank == 0 else None
+
+    def save(self, filename):
+        return bool(_pkg().lib().pf_dist_save(self._h, filename.encode()))
+
+    def stats(self):
+        st = _pkg().DistStats()
+        _pkg().lib().pf_dist_last_stats(self._h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in st._fields_}
 
 
 class GpuEngine:
