@@ -427,7 +427,7 @@ def main():
     # strong sharding: what a rank renders beyond its share, and the timed seam exchange
     if strong:
         sh = importlib.import_module("pi_slam_fusion_amd.sharding")
-        info = guarded(sh.strong_report, pf, m, dist, opt, owned_tiles, base[W:W + K])
+        info = guarded(sh.strong_report, m, rank, N, os.environ.get("PF_DIST_BACKEND", "nccl"))
         if rank == 0:
             out["sharding"] = info
 

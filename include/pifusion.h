@@ -205,6 +205,9 @@ int     pf_profile_enable(pf_map* m, int mode);
 int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
                         double* alg_bytes);
 int     pf_profile_reset(pf_map* m);
+/* sharding overhead since creation: {frames that put pixels on this rank, level-0 pixels computed (owned tiles + pyramid
+ * halo, fused path), tile pixels owned in those frames, tiles held}: [1]/[2] is the halo recompute factor of a shard  */
+int     pf_render_stats(pf_map* m, double out4[4]);
 /* frames rendered / rejected since creation */
 int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
 /* Allocator hint, no reference counterpart (MultiBandMap2DCPUEle's cv::Mat tiles, MultiBandMap2DCPU.h:32-51,

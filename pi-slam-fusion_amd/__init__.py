@@ -115,6 +115,7 @@ def lib():
     L.pf_profile_reset.argtypes = [vp]
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
+    L.pf_render_stats.argtypes = [vp, dp]
     _lib = L
     return L
 
@@ -349,6 +350,11 @@ class Map2D:
     def reserve_tiles(self, n_tiles):
         """Allocator hint: HBM for n_tiles more tiles now (see pf_reserve_tiles)."""
         return bool(lib().pf_reserve_tiles(self._h, int(n_tiles)))
+
+    def render_stats(self):
+        o = (C.c_double * 4)()
+        lib().pf_render_stats(self._h, o)
+        return {"frames_with_pixels": int(o[0]), "level0_px": o[1], "owned_px": o[2], "tiles_held": int(o[3])}
 
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

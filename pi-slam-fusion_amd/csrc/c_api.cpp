@@ -144,6 +144,7 @@ int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, lo
 { return m ? m->impl.profile_read(cap, names, total_ms, launches, alg_bytes) : 0; }
 int pf_profile_reset(pf_map* m) { if (!m) return 0; m->impl.profile_reset(); return 1; }
 int pf_reserve_tiles(pf_map* m, long long n_tiles) { return m && m->impl.reserve_tiles(n_tiles) ? 1 : 0; }
+int pf_render_stats(pf_map* m, double out4[4]) { if (!m || !out4) return 0; m->impl.render_stats(out4); return 1; }
 int pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped) { if (!m) return 0; m->impl.stats(rendered, rejected, dropped); return 1; }
 
 }  // extern "C"

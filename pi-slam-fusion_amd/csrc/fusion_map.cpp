@@ -150,6 +150,7 @@ FusionMap::~FusionMap()
     for (auto& s : slots_) { if (s.dev) (void)hipFree(s.dev); if (s.consumed) (void)hipEventDestroy(s.consumed); }
     for (int i = 0; i < kTableRing; i++) {
         if (table_host_[i]) (void)hipHostFree(table_host_[i]);
+        if (mask_host_[i]) (void)hipHostFree(mask_host_[i]);
         table_dev_[i].release();
         if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
         if (i < kMarks && mark_ev_[i]) (void)hipEventDestroy(mark_ev_[i]);
@@ -242,6 +243,12 @@ bool FusionMap::reserve_tiles(long long n_tiles)
     for (auto& f : fresh) HIP_OK(hipMemsetAsync(f.first, 0, f.second, stream_));
     HIP_OK(hipStreamSynchronize(stream_));
     return true;
+}
+
+void FusionMap::render_stats(double out[4])
+{
+    std::lock_guard<std::mutex> l(mu_);
+    out[0] = (double)n_with_pixels_; out[1] = px_level0_; out[2] = px_owned_; out[3] = (double)store_.size();
 }
 
 void FusionMap::stats(long long* rendered, long long* rejected, long long* dropped)
@@ -557,6 +564,14 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
             }
     if (bx0 >= bx1) return true;                // nothing of this frame lands on this shard
+    {   // what this rank renders beyond its share (bench --shard strong): owned tile pixels vs the level-0 window
+        int owned = 0;
+        for (int y = 0; y < ty; y++)
+            for (int x = 0; x < tx; x++)
+                owned += tile_owner(opt_.shard_count, opt_.shard_block, xminInt + x + off_x_, yminInt + y + off_y_) == opt_.shard_rank;
+        px_owned_ += (double)owned * kElePixels * kElePixels;
+        n_with_pixels_++;
+    }
 
     // per-level windows: Gaussian level i must be valid on need[i] so that the
     // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
@@ -680,13 +695,81 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             clampw(y0, y1, rows, C[i].y0, C[i].y1);
         }
         const double E = 3 * es + 4;
+        // A shard's tiles are scattered hash cells, and the compute regions above are their bounding box: mark the 64x32
+        // blocks that something owned depends on, per level, with the same recursion applied per cell -- the others exit at
+        // once.  (Unsharded: every block is needed, no mask.)
+        const uint8_t* masks[kMaxLevels] = {};
+        double owned_tiles = (double)(bx1 - bx0) * (by1 - by0), blocks_run0 = 0;
+        if (opt_.shard_count > 1 && opt_.fused == 1) {
+            struct Cell { int x0, y0, x1, y1; };
+            std::unordered_map<uint64_t, Cell> cells;
+            const int B = opt_.shard_block;
+            owned_tiles = 0;
+            for (int y = 0; y < ty; y++)
+                for (int x = 0; x < tx; x++) {
+                    const int sx = xminInt + x + off_x_, sy = yminInt + y + off_y_;
+                    if (tile_owner(opt_.shard_count, B, sx, sy) != opt_.shard_rank) continue;
+                    owned_tiles++;
+                    const uint64_t key = ((uint64_t)(uint32_t)floordiv(sx, B) << 32) | (uint32_t)floordiv(sy, B);
+                    auto it = cells.find(key);
+                    if (it == cells.end()) cells.emplace(key, Cell{ x, y, x + 1, y + 1 });
+                    else { Cell& c = it->second; c.x0 = std::min(c.x0, x); c.y0 = std::min(c.y0, y); c.x1 = std::max(c.x1, x + 1); c.y1 = std::max(c.y1, y + 1); }
+                }
+            size_t need_bytes = 0, off[kMaxLevels];
+            int nbx[kMaxLevels], nby[kMaxLevels];
+            for (int i = 0; i < L; i++) {
+                nbx[i] = (C[i].x1 - C[i].x0 + 63) / 64; nby[i] = (C[i].y1 - C[i].y0 + 31) / 32;
+                off[i] = need_bytes; need_bytes += ((size_t)std::max(nbx[i], 0) * std::max(nby[i], 0) + 63) / 64 * 64;
+            }
+            if (mask_cap_ < need_bytes) {
+                HIP_OK(sync_all());
+                mask_cap_ = need_bytes * 2;
+                for (int k = 0; k < kTableRing; k++) {
+                    if (mask_host_[k]) (void)hipHostFree(mask_host_[k]);
+                    HIP_OK(hipHostMalloc((void**)&mask_host_[k], mask_cap_, hipHostMallocNonCoherent));
+                    HIP_OK(hipHostGetDevicePointer((void**)&mask_ptr_[k], mask_host_[k], 0));
+                }
+            }
+            uint8_t* mk = mask_host_[ring];
+            std::memset(mk, 0, need_bytes);
+            for (auto& kv : cells) {
+                // N[i]: where Gaussian level i is needed for this cell's tiles (pixel-exact: pyrDown reads [2p-2, 2p+2],
+                // pyrUp +-1 -- the recursion of `need` above, per cell).  The level-i block at b runs iff it holds owned
+                // pixels or its part of level i+1 lies in N[i+1]; what else it computes from unproduced input is never read.
+                Win N[kMaxLevels];
+                for (int i = L; i >= 0; i--) {
+                    const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
+                    int x0 = kv.second.x0 * ts, x1 = kv.second.x1 * ts, y0 = kv.second.y0 * ts, y1 = kv.second.y1 * ts;
+                    if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
+                    if (i < L) {
+                        x0 = std::min(x0, 2 * N[i + 1].x0 - 2); x1 = std::max(x1, 2 * N[i + 1].x1 + 1);
+                        y0 = std::min(y0, 2 * N[i + 1].y0 - 2); y1 = std::max(y1, 2 * N[i + 1].y1 + 1);
+                    }
+                    clampw(x0, x1, cols, N[i].x0, N[i].x1);
+                    clampw(y0, y1, rows, N[i].y0, N[i].y1);
+                }
+                for (int i = 0; i < L; i++) {
+                    const int ts = kElePixels >> i;
+                    int x0 = std::min(kv.second.x0 * ts, 2 * N[i + 1].x0), x1 = std::max(kv.second.x1 * ts, 2 * N[i + 1].x1);
+                    int y0 = std::min(kv.second.y0 * ts, 2 * N[i + 1].y0), y1 = std::max(kv.second.y1 * ts, 2 * N[i + 1].y1);
+                    x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
+                    if (x0 >= x1 || y0 >= y1) continue;
+                    const int gx0 = (x0 - C[i].x0) / 64, gy0 = (y0 - C[i].y0) / 32, gx1 = (x1 - C[i].x0 + 63) / 64, gy1 = (y1 - C[i].y0 + 31) / 32;
+                    for (int gy = gy0; gy < gy1; gy++) std::memset(mk + off[i] + (size_t)gy * nbx[i] + gx0, 1, (size_t)(gx1 - gx0));
+                }
+            }
+            for (int i = 0; i < L; i++) masks[i] = mask_ptr_[ring] + off[i];
+            for (size_t k = 0; k < (size_t)nbx[0] * nby[0]; k++) blocks_run0 += mk[off[0] + k];
+            px_level0_ += blocks_run0 * 64 * 32;
+        } else
+            px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
         if (opt_.fused == 1) {
             // one launch per keyframe: this frame's level 0 plus the pending upper levels of the frames before it
             PipeFrame cur;
             cur.valid = true; cur.ring = ring; cur.tx = tx; cur.crows = crows; cur.ccols = ccols;
             for (int i = 0; i < L; i++) {
-                cur.C[i] = C[i];
-                const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
+                cur.C[i] = C[i]; cur.mask[i] = masks[i];
+                const double ts = kElePixels >> i, n = owned_tiles * ts * ts;
                 // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
                 cur.bytes[i] = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0) + (i == 0 ? (double)a.src_cn * f.rows * f.cols : 0);
             }
@@ -819,7 +902,7 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.cx0 = fr.C[i].x0; q.cy0 = fr.C[i].y0; q.cx1 = fr.C[i].x1; q.cy1 = fr.C[i].y1;
         q.tiles_x = fr.tx; q.top_select = top; q.write_next = !top; q.from_warp = (i == 0);
         q.gw_in = i == 0 ? nullptr : in[i].p; q.gw_out = top ? nullptr : out[i + 1].p;
-        q.table = table_ptr_[fr.ring];
+        q.table = table_ptr_[fr.ring]; q.mask = fr.mask[i];
         bytes += fr.bytes[i];
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid

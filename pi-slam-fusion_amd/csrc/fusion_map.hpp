@@ -117,6 +117,7 @@ public:
     int  profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes);
     void profile_reset();
     void stats(long long* rendered, long long* rejected, long long* dropped);
+    void render_stats(double out[4]);
     bool reserve_tiles(long long n_tiles);
     const pf_options& options() const { return opt_; }
 
@@ -162,6 +163,9 @@ private:
     hipStream_t prof_stream_ = nullptr;
     static constexpr int kUpperStreams = 1;         // streams shared by pyramid levels >= 1
     uint64_t*  table_host_[kTableRing]{};
+    uint8_t*   mask_host_[kTableRing]{};            // per-frame block masks of a shard (pinned, read in place like the tables)
+    uint8_t*   mask_ptr_[kTableRing]{};
+    size_t     mask_cap_ = 0;
     uint64_t*  table_ptr_[kTableRing]{};            // what the kernels dereference: the host table itself (zero copy) or table_dev_
     bool       table_zero_copy_ = true;
     DevBuf     table_dev_[kTableRing];
@@ -184,7 +188,7 @@ private:
 
     // pipelined level launches (opt_.fused == 1): pipe_[s] is the frame whose level s runs in the next launch
     struct Win { int x0, x1, y0, y1; };
-    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels]; };
+    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels]; const uint8_t* mask[kMaxLevels]; };
     PipeFrame pipe_[kMaxLevels];
     unsigned long long launch_seq_ = 0;             // parity selects the GW buffer set a launch writes
     bool flushing_ = false;
@@ -211,7 +215,8 @@ private:
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};
     ProfRec prof_cur_{};
-    long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0;
+    long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0, n_with_pixels_ = 0;
+    double px_level0_ = 0, px_owned_ = 0;           // level-0 pixels computed (with halo) / tile pixels owned, over the frames rendered
 };
 
 // PNG (zlib) / PPM writer for save()

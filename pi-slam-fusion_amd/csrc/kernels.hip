@@ -1082,6 +1082,7 @@ struct LevelJob {
     const void*  gw_in;
     void*        gw_out;
     const uint64_t* table;     // the tile table of the job's frame
+    const uint8_t*  mask;      // see LevelLaunch::mask
     int first;                 // first block id
     int from_warp;             // level 0: stage A is the warp of the launch's frame
 };
@@ -1108,10 +1109,12 @@ __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp w
     const LevelJob& J = batch.job[j];
     const int nblk = J.g.nbx * J.g.nby;
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
+    const int bb = xcd_order(b, nblk);
+    if (J.mask && !J.mask[bb]) return;                         // a shard: no tile of this rank depends on the block
     unsigned long long* st = nullptr;
     if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
     level3_block<F32, LBH, LNT, STAMP>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                       J.table, xcd_order(b, nblk), st);
+                                       J.table, bb, st);
 }
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1183,7 +1186,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         J.g.nbx = (q.cx1 - q.cx0 + LBW - 1) / LBW; J.g.nby = (q.cy1 - q.cy0 + BH - 1) / BH;
         if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
-        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
+        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.mask = q.mask; J.from_warp = q.from_warp;
         // job 0 has its own block numbering, jobs 1.. share one (see k_levels)
         const int padded = (J.g.nbx * J.g.nby + 7) & ~7;
         if (batch.njobs == 0) { J.first = 0; first_blocks = padded; }

@@ -83,6 +83,8 @@ struct LevelLaunch {
     bool top_select, write_next, from_warp;
     const void* gw_in; void* gw_out;
     const uint64_t* table;
+    const uint8_t* mask;            // nullptr, or one byte per 64x32 block of the compute region (row-major): 0 = nothing of this
+                                    // rank's tiles depends on the block (tile-sharded canvases), skip it
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);      // diagnostics (PF_STAMP=1)

@@ -118,6 +118,51 @@ class DistMap:
         return {k: getattr(st, k) for k, _ in st._fields_}
 
 
+def strong_report(m, rank, world, backend, group=None):
+    """bench.py --shard strong: what sharding one sortie costs -- per-rank halo recompute, and the seam exchange timed:
+    draw() of every tile across ranks, then save()'s gather + collapse on rank 0.  Collective; rank 0 gets the record."""
+    import time
+    d = DistMap(m, rank, world, backend="nccl" if backend == "nccl" else "host", group=group)
+    rs = m.render_stats()
+    m.sync()
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter(); coords, _ = d.blend_changed(); t_blend = time.perf_counter() - t0
+    st_b = d.stats()
+    if world > 1:
+        dist.barrier(group)
+    t0 = time.perf_counter(); saved = d.save_to_memory(); t_save = time.perf_counter() - t0
+    st_s = d.stats()
+    mine = {"rank": rank, "tiles": len(m.tiles()), "blended": len(coords), "render": rs, "blend_s": t_blend, "blend": st_b,
+            "save_s": t_save, "save": st_s, "mosaic": None if saved is None else list(saved[0].shape[:2])}
+    got = [None] * world
+    if world > 1:
+        dist.all_gather_object(got, mine, group=group)
+    else:
+        got = [mine]
+    d.close()
+    if rank != 0:
+        return None
+    seam = sum(g["blend"]["bytes_received"] for g in got)
+    xms = max(g["blend"]["exchange_ms"] for g in got)
+    gathered = got[0]["save"]["bytes_received"]
+    return {
+        "transport": "rccl" if backend == "nccl" else "host-buffer hook over torch.distributed (%s)" % backend,
+        "tiles_per_rank": [g["tiles"] for g in got],
+        "halo_recompute_factor_per_rank": [round(g["render"]["level0_px"] / max(g["render"]["owned_px"], 1.0), 3) for g in got],
+        "frames_with_pixels_per_rank": [g["render"]["frames_with_pixels"] for g in got],
+        "draw": {"tiles": sum(g["blended"] for g in got), "seconds_max": round(max(g["blend_s"] for g in got), 4),
+                 "seam_bytes": seam, "strips": sum(g["blend"]["strips_received"] for g in got),
+                 "exchange_ms_max": round(xms, 3), "seam_GBps": round(seam / max(xms, 1e-6) / 1e6, 2),
+                 "pack_ms_max": round(max(g["blend"]["pack_ms"] for g in got), 3),
+                 "blend_ms_max": round(max(g["blend"]["compute_ms"] for g in got), 3)},
+        "save": {"mosaic": got[0]["mosaic"], "seconds_rank0": round(got[0]["save_s"], 4), "gathered_bytes": gathered,
+                 "gather_ms": round(got[0]["save"]["exchange_ms"], 3),
+                 "gather_GBps": round(gathered / max(got[0]["save"]["exchange_ms"], 1e-6) / 1e6, 2),
+                 "collapse_ms": round(got[0]["save"]["compute_ms"], 3)},
+    }
+
+
 class GpuEngine:
     """Adapter of a pi_slam_fusion_amd.Map2D to the exchange interface (device tensors)."""
 
