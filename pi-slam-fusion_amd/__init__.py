@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpifusion.so")
+LIB_PATH = os.environ.get("PF_LIB") or os.path.join(_HERE, "libpifusion.so")      # PF_LIB: another build of the same library (A/B runs)
 ELE_PIXELS = 256
 
 # Map2D::Map2DType (Map2D.h:83)

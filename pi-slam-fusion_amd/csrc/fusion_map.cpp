@@ -702,6 +702,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         double owned_tiles = (double)(bx1 - bx0) * (by1 - by0), blocks_run0 = 0;
         if (opt_.shard_count > 1 && opt_.fused == 1) {
             struct Cell { int x0, y0, x1, y1; };
+            const int BHr = level_block_rows(lay_.f32 != 0);
             std::unordered_map<uint64_t, Cell> cells;
             const int B = opt_.shard_block;
             owned_tiles = 0;
@@ -718,7 +719,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             size_t need_bytes = 0, off[kMaxLevels];
             int nbx[kMaxLevels], nby[kMaxLevels];
             for (int i = 0; i < L; i++) {
-                nbx[i] = (C[i].x1 - C[i].x0 + 63) / 64; nby[i] = (C[i].y1 - C[i].y0 + 31) / 32;
+                nbx[i] = (C[i].x1 - C[i].x0 + 63) / 64; nby[i] = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
                 off[i] = need_bytes; need_bytes += ((size_t)std::max(nbx[i], 0) * std::max(nby[i], 0) + 63) / 64 * 64;
             }
             if (mask_cap_ < need_bytes) {
@@ -754,13 +755,13 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                     int y0 = std::min(kv.second.y0 * ts, 2 * N[i + 1].y0), y1 = std::max(kv.second.y1 * ts, 2 * N[i + 1].y1);
                     x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
                     if (x0 >= x1 || y0 >= y1) continue;
-                    const int gx0 = (x0 - C[i].x0) / 64, gy0 = (y0 - C[i].y0) / 32, gx1 = (x1 - C[i].x0 + 63) / 64, gy1 = (y1 - C[i].y0 + 31) / 32;
+                    const int gx0 = (x0 - C[i].x0) / 64, gy0 = (y0 - C[i].y0) / BHr, gx1 = (x1 - C[i].x0 + 63) / 64, gy1 = (y1 - C[i].y0 + BHr - 1) / BHr;
                     for (int gy = gy0; gy < gy1; gy++) std::memset(mk + off[i] + (size_t)gy * nbx[i] + gx0, 1, (size_t)(gx1 - gx0));
                 }
             }
             for (int i = 0; i < L; i++) masks[i] = mask_ptr_[ring] + off[i];
             for (size_t k = 0; k < (size_t)nbx[0] * nby[0]; k++) blocks_run0 += mk[off[0] + k];
-            px_level0_ += blocks_run0 * 64 * 32;
+            px_level0_ += blocks_run0 * 64 * BHr;
         } else
             px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
         if (opt_.fused == 1) {

@@ -32,6 +32,11 @@ __device__ __forceinline__ double clamp_int_range(double v)
 // tile slots are reached through integers of the tile table: tell the compiler they are global
 // memory, otherwise every tile access becomes a FLAT instruction
 #define PF_GLOBAL __attribute__((address_space(1)))
+#ifdef PF_NT_STORES
+#define PF_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define PF_STORE(p, v) (*(p) = (v))
+#endif
 
 template <bool F32> struct Pix;
 template <> struct Pix<false> { using T = short; using WT = int;   static constexpr int bytes = 2; };
@@ -542,9 +547,10 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
         // dependent rounds of four loads held a workgroup slot for ~9000 cycles (tools/stamp_phases.py).
         const int i0 = tid, i1 = i0 + LNT, i2 = i1 + LNT, i3 = i2 + LNT, i4 = i3 + LNT, i5 = i4 + LNT;
         const Px t0 = gin[gaddr(i0)], t1 = gin[gaddr(i1)], t2 = gin[gaddr(i2)], t3 = gin[gaddr(i3)], t4 = gin[gaddr(i4)], t5 = gin[gaddr(i5)];
-        Aflat[laddr(i0)] = t0; Aflat[laddr(i1)] = t1; Aflat[laddr(i2)] = t2; Aflat[laddr(i3)] = t3; Aflat[laddr(i4)] = t4;
+        Aflat[laddr(i0)] = t0; Aflat[laddr(i1)] = t1; Aflat[laddr(i2)] = t2; Aflat[laddr(i3)] = t3;
+        if (i4 < LAH * LAW) Aflat[laddr(i4)] = t4;
         if (i5 < LAH * LAW) Aflat[laddr(i5)] = t5;
-        static_assert(LAH * LAW > 5 * LNT, "i4 is always inside the tile");
+        static_assert(LAH * LAW > 4 * LNT, "i3 is always inside the tile");
         return;
     }
 #pragma unroll
@@ -773,7 +779,7 @@ __device__ __forceinline__ void phase_stamp(unsigned long long* st, int slot)
     }
 }
 
-template <bool F32, int LBH, int LNT, bool STAMP = false>
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2>
 __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
                                              const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
                                              PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table, const int b,
@@ -792,7 +798,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     auto Aat = [&](int r, int c) -> Px& { return A[r][c & 1][c >> 1]; };
     // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
     // workgroups per CU, int16 under 32 for four
-    static_assert(sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget");
+    static_assert(LBH != 32 || sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget (64x32 blocks)");
+    static_assert(LBH != 64 || sizeof(A) + sizeof(Bt) <= 64 * 1280, "LDS budget (64x64 blocks: two workgroups of 1024 threads per CU)");
 
     const int bx = b % g.nbx, by = b / g.nbx;
     const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
@@ -820,6 +827,32 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             const bool near101 = g.rows >= 8 && g.cols >= 8;
             if (!inner) x = near101 ? border_reflect101_near(x, g.cols) : border_reflect101(x, g.cols);
             const WarpCol col = warp_col(wa, x);
+            auto row_of = [&](int r) {
+                int y = ay0 + r;
+                if (!inner) y = near101 ? border_reflect101_near(y, g.rows) : border_reflect101(y, g.rows);
+                return y;
+            };
+            if constexpr (ILP == 3) {
+                // three rows per step: nine loads of a thread in flight -- fewer waves are needed to keep the vector unit
+                // fed while other workgroups of the CU sit in their memory-bound stages
+                for (int r = r0; r < LAH; r += 3 * RS) {
+                    const int rb = r + RS, rc = r + 2 * RS;
+                    const bool hasb = rb < LAH, hasc = rc < LAH;
+                    const int y = row_of(r), yb = row_of(hasb ? rb : r), yc = row_of(hasc ? rc : r);
+                    if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; if (hasc) Aat(rc, c) = z; continue; }
+                    const WarpTaps ta = warp_fetch(src, wa, col, y);
+                    const WarpTaps tb = warp_fetch(src, wa, col, yb);
+                    if (__builtin_amdgcn_ballot_w64(hasc) != 0) {
+                        const WarpTaps tc = warp_fetch(src, wa, col, yc);
+                        Aat(r, c) = warp_finish<F32>(ta, wa.cn);
+                        if (hasb) Aat(rb, c) = warp_finish<F32>(tb, wa.cn);
+                        if (hasc) Aat(rc, c) = warp_finish<F32>(tc, wa.cn);
+                    } else {
+                        Aat(r, c) = warp_finish<F32>(ta, wa.cn);
+                        if (hasb) Aat(rb, c) = warp_finish<F32>(tb, wa.cn);
+                    }
+                }
+            } else
             // two rows per step: the second pixel's coordinates and loads overlap the first one's loads
             for (int r = r0; r < LAH; r += 2 * RS) {
                 const int rb = r + RS;
@@ -1018,10 +1051,12 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             const float o01c = g01.c[2] - (ho2[0] + ho2[1] * 6 + ho2[2]) * (1.f / 64);
             const float o10c = g10.c[2] - ((he2[1] + he2[2]) * 4) * (1.f / 64);
             const float o11c = g11.c[2] - ((ho2[1] + ho2[2]) * 4) * (1.f / 64);
-            if (s00) { dl[0] = o00L.x; dl[1] = o00L.y; dl[2] = o00c; dw[0] = g00.w; }
-            if (s01) { dl[3] = o01L.x; dl[4] = o01L.y; dl[5] = o01c; dw[1] = g01.w; }
-            if (s10) { dl[3 * ts] = o10L.x; dl[3 * ts + 1] = o10L.y; dl[3 * ts + 2] = o10c; dw[ts] = g10.w; }
-            if (s11) { dl[3 * ts + 3] = o11L.x; dl[3 * ts + 4] = o11L.y; dl[3 * ts + 5] = o11c; dw[ts + 1] = g11.w; }
+            // Laplacian payload: written once, read again only by blend/save -- non-temporal when PF_NT_STORES is defined (A/B)
+            auto st3 = [&](T PF_GLOBAL* p, float a, float b, float c2) { PF_STORE(p, a); PF_STORE(p + 1, b); PF_STORE(p + 2, c2); };
+            if (s00) { st3(dl, o00L.x, o00L.y, o00c); dw[0] = g00.w; }
+            if (s01) { st3(dl + 3, o01L.x, o01L.y, o01c); dw[1] = g01.w; }
+            if (s10) { st3(dl + 3 * ts, o10L.x, o10L.y, o10c); dw[ts] = g10.w; }
+            if (s11) { st3(dl + 3 * ts + 3, o11L.x, o11L.y, o11c); dw[ts + 1] = g11.w; }
             return;
         }
     }
@@ -1048,10 +1083,11 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         o10[k] = sat_sub(g10.c[k], cast_up((he[1][k] + he[2][k]) * 4));
         o11[k] = sat_sub(g11.c[k], cast_up((ho[1][k] + ho[2][k]) * 4));
     }
-    if (s00) { dl[0] = o00[0]; dl[1] = o00[1]; dl[2] = o00[2]; dw[0] = g00.w; }
-    if (s01) { dl[3] = o01[0]; dl[4] = o01[1]; dl[5] = o01[2]; dw[1] = g01.w; }
-    if (s10) { dl[3 * ts] = o10[0]; dl[3 * ts + 1] = o10[1]; dl[3 * ts + 2] = o10[2]; dw[ts] = g10.w; }
-    if (s11) { dl[3 * ts + 3] = o11[0]; dl[3 * ts + 4] = o11[1]; dl[3 * ts + 5] = o11[2]; dw[ts + 1] = g11.w; }
+    auto st3g = [&](T PF_GLOBAL* p, const T* v) { PF_STORE(p, v[0]); PF_STORE(p + 1, v[1]); PF_STORE(p + 2, v[2]); };
+    if (s00) { st3g(dl, o00); dw[0] = g00.w; }
+    if (s01) { st3g(dl + 3, o01); dw[1] = g01.w; }
+    if (s10) { st3g(dl + 3 * ts, o10); dw[ts] = g10.w; }
+    if (s11) { st3g(dl + 3 * ts + 3, o11); dw[ts + 1] = g11.w; }
 }
 
 // XCD-aware block order: consecutive block ids go round-robin to the 8 XCDs, so block id b is mapped
@@ -1088,7 +1124,7 @@ struct LevelJob {
 };
 struct LevelBatch { int njobs, upper_groups, total_groups, sequential; LevelJob job[kMaxLevels]; };      // job[k].first, k >= 1: block offset among the upper-level jobs
 
-template <bool F32, int LBH, int LNT, bool STAMP = false>
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2>
 __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
@@ -1113,8 +1149,8 @@ __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp w
     if (J.mask && !J.mask[bb]) return;                         // a shard: no tile of this rank depends on the block
     unsigned long long* st = nullptr;
     if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
-    level3_block<F32, LBH, LNT, STAMP>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                       J.table, bb, st);
+    level3_block<F32, LBH, LNT, STAMP, ILP>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
+                                            J.table, bb, st);
 }
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1175,7 +1211,7 @@ constexpr int kStampBlocks = 1 << 16;
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
 {
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
-    constexpr int BH = 32;
+    const int BH = level_block_rows(lay.f32 != 0);
     LevelBatch batch{};
     int first_blocks = 0, upper_blocks = 0;
     for (int k = 0; k < njobs; k++) {
@@ -1208,18 +1244,33 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         w.plain = plain_homography(*wa);
     }
     static const bool stamp = getenv("PF_STAMP") != nullptr;
+    static const int ilp = getenv("PF_A_ILP") ? atoi(getenv("PF_A_ILP")) : 3;       // measured: 3 rows per step +1.2 % over 2 (both pyramid types)
+    unsigned long long* st = nullptr;
     if (stamp) {
         if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
         if (g_stamp_buf && nblocks <= kStampBlocks) {
             (void)hipMemsetAsync(g_stamp_buf, 0, (size_t)kStampBlocks * 64, s);
             g_stamp_blocks = nblocks;
-            if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, g_stamp_buf);
-            else         hipLaunchKernelGGL((k_levels<false, BH, 512, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, g_stamp_buf);
-            return;
+            st = g_stamp_buf;
         }
     }
-    if (lay.f32) hipLaunchKernelGGL((k_levels<true, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src, (unsigned long long*)nullptr);
-    else         hipLaunchKernelGGL((k_levels<false, BH, 512>), dim3(nblocks), dim3(512), 0, s, batch, w, src, (unsigned long long*)nullptr);
+#define PF_GO(F, H, T, S, I) hipLaunchKernelGGL((k_levels<F, H, T, S, I>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
+    if (BH == 64) {                                   // int16 only (see level_block_rows)
+        if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);
+    } else if (lay.f32) {
+        if (st) PF_GO(true, 32, 512, true, 3); else if (ilp == 3) PF_GO(true, 32, 512, false, 3); else PF_GO(true, 32, 512, false, 2);
+    } else {
+        if (st) PF_GO(false, 32, 512, true, 3); else if (ilp == 3) PF_GO(false, 32, 512, false, 3); else PF_GO(false, 32, 512, false, 2);
+    }
+#undef PF_GO
+}
+
+// rows of a level-kernel block: 32 (512 threads); PF_BLOCK64=1: 64 rows x 1024 threads for the int16 pyramids, whose
+// 12-byte LDS pixels leave room for two such workgroups per CU (halo recompute 1.23 instead of 1.35); fp32 does not fit
+int level_block_rows(bool f32)
+{
+    static const bool b64 = getenv("PF_BLOCK64") != nullptr;
+    return (!f32 && b64) ? 64 : 32;
 }
 
 // diagnostics: the stamps of the most recent PF_STAMP launch (8 u64 per workgroup: start, A done, barrier 1 passed, B done,

@@ -87,7 +87,8 @@ struct LevelLaunch {
                                     // rank's tiles depends on the block (tile-sharded canvases), skip it
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
-int  read_phase_stamps(unsigned long long* out, int cap_blocks);      // diagnostics (PF_STAMP=1)
+int  read_phase_stamps(unsigned long long* out, int cap_blocks);
+int  level_block_rows(bool f32);                                     // block height of the pipelined level kernel (fused = 1)      // diagnostics (PF_STAMP=1)
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
 void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,
