@@ -30,8 +30,7 @@ int main()
             for (int r = 0; r < 5; r++) hipLaunchKernelGGL(k_wg, dim3(n), dim3(sh[0]), sh[1], 0, out, work);
             CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            std::printf("threads %4d  LDS %6d B  work %4d  %6d workgroups: %7.2f us per launch, %6.3f us per workgroup-slot-round (%d resident per CU by LDS/waves)\n",
-                        sh[0], sh[1], work, n, ms * 1e3 / 5, 0.0, 0);
+            std::printf("threads %4d  LDS %6d B  work %4d  %6d workgroups: %7.2f us per launch\n", sh[0], sh[1], work, n, ms * 1e3 / 5);
         }
     }
     return 0;
