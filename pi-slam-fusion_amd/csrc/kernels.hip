@@ -357,11 +357,11 @@ struct WarpTaps {
     uint32_t flags;
 };
 
-__device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
+// X0, Y0, W0: the coordinate terms of the pixel's row and 64-wide coordinate block (M0*xb + M1*y + M2 ...), formed by the
+// caller: per pixel (warp_fetch) or once per workgroup in a row table (level3_block, ILP 4)
+__device__ __forceinline__ WarpTaps warp_fetch_pre(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col,
+                                                   const double X0, const double Y0, const double W0)
 {
-    const double X0 = col.m0xb + a.M[1] * y + a.M[2];
-    const double Y0 = col.m3xb + a.M[4] * y + a.M[5];
-    const double W0 = col.m6xb + a.M[7] * y + a.M[8];
     const double W  = W0 + col.m6x1;
     const double xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
     // nearest coordinate p = (X0+M0*x1)*(1/W); the 1/32-px coordinate (X0+M0*x1)*(32/W) equals 32*p
@@ -423,6 +423,11 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y;
     t.X = X; t.Y = Y; t.flags = flags;
     return t;
+}
+
+__device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
+{
+    return warp_fetch_pre(src, a, col, col.m0xb + a.M[1] * y + a.M[2], col.m3xb + a.M[4] * y + a.M[5], col.m6xb + a.M[7] * y + a.M[8]);
 }
 
 template <bool F32>
@@ -789,7 +794,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
-    static_assert(LNT == 32 * (LBH / 2), "one thread per 2x2 output quad");
+    static_assert(LNT >= 32 * (LBH / 2), "one thread per 2x2 output quad (threads beyond that help in stages A and B only)");
     struct Bx { T c[F32 ? 3 : 4]; };                            // stage D needs G_{i+1} only, not W_{i+1}
     // A is split by column parity, [row][parity][column / 2]: the pyrDown taps of neighbouring threads (2q .. 2q+4)
     // and the 2x2 quads of stage D are then 16 bytes apart per lane instead of 32 -- no LDS bank conflicts
@@ -812,7 +817,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     // this thread's output quad and its tile-table entry (a quad never straddles tiles)
     const int qx = tid & 31, qy = tid >> 5;
     const int dx0 = x0 + 2 * qx, dy0 = y0 + 2 * qy;
-    uint64_t ent = (dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
+    uint64_t ent = (tid < 32 * (LBH / 2) && dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
 
     // ---- A
     if (FROM_WARP) {
@@ -821,17 +826,21 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         const bool inner = ax0 >= 0 && ax0 + LAW <= g.cols && ay0 >= 0 && ay0 + LAH <= g.rows;
         constexpr int RS = LNT / LAW;
         const int r0 = tid / LAW, c = tid - r0 * LAW;
-        if (r0 < RS) {
-            int x = ax0 + c;
-            // halo coordinates lie in [-4, len + 3): one reflection unless the level is only a few pixels wide
-            const bool near101 = g.rows >= 8 && g.cols >= 8;
+        // halo coordinates lie in [-4, len + 3): one reflection unless the level is only a few pixels wide
+        const bool near101 = g.rows >= 8 && g.cols >= 8;
+        auto col_of = [&](int cc) {
+            int x = ax0 + cc;
             if (!inner) x = near101 ? border_reflect101_near(x, g.cols) : border_reflect101(x, g.cols);
+            return x;
+        };
+        auto row_of = [&](int r) {
+            int y = ay0 + r;
+            if (!inner) y = near101 ? border_reflect101_near(y, g.rows) : border_reflect101(y, g.rows);
+            return y;
+        };
+        if (r0 < RS) {
+            const int x = col_of(c);
             const WarpCol col = warp_col(wa, x);
-            auto row_of = [&](int r) {
-                int y = ay0 + r;
-                if (!inner) y = near101 ? border_reflect101_near(y, g.rows) : border_reflect101(y, g.rows);
-                return y;
-            };
             if constexpr (ILP == 3) {
                 // three rows per step: nine loads of a thread in flight -- fewer waves are needed to keep the vector unit
                 // fed while other workgroups of the CU sit in their memory-bound stages
