@@ -804,7 +804,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
     // workgroups per CU, int16 under 32 for four
     static_assert(LBH != 32 || sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget (64x32 blocks)");
-    static_assert(LBH != 64 || sizeof(A) + sizeof(Bt) <= 64 * 1280, "LDS budget (64x64 blocks: two workgroups of 1024 threads per CU)");
+    static_assert(LBH != 64 || sizeof(A) + sizeof(Bt) <= (F32 ? 128 : 64) * 1280, "LDS budget (64x64 blocks of 1024 threads: int16 two per CU, fp32 one)");
 
     const int bx = b % g.nbx, by = b / g.nbx;
     const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
@@ -1264,8 +1264,9 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         }
     }
 #define PF_GO(F, H, T, S, I) hipLaunchKernelGGL((k_levels<F, H, T, S, I>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
-    if (BH == 64) {                                   // int16 only (see level_block_rows)
-        if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);
+    if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)
+        if (lay.f32) { if (ilp == 3) PF_GO(true, 64, 1024, false, 3); else PF_GO(true, 64, 1024, false, 2); }
+        else if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);
     } else if (lay.f32) {
         if (st) PF_GO(true, 32, 512, true, 3); else if (ilp == 3) PF_GO(true, 32, 512, false, 3); else PF_GO(true, 32, 512, false, 2);
     } else {
@@ -1274,12 +1275,14 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
 #undef PF_GO
 }
 
-// rows of a level-kernel block: 32 (512 threads); PF_BLOCK64=1: 64 rows x 1024 threads for the int16 pyramids, whose
-// 12-byte LDS pixels leave room for two such workgroups per CU (halo recompute 1.23 instead of 1.35); fp32 does not fit
+// rows of a level-kernel block: 32 (512 threads, three workgroups per CU).  PF_BLOCK64=1 (A/B): 64 rows x 1024 threads, halo
+// recompute 1.23 instead of 1.35 -- int16 (12-byte LDS pixels) fits two such workgroups per CU by LDS, fp32 (96 KB) one.
+// Measured on MI355X, cfg-A: int16 -23 %, fp32 -18 %
 int level_block_rows(bool f32)
 {
     static const bool b64 = getenv("PF_BLOCK64") != nullptr;
-    return (!f32 && b64) ? 64 : 32;
+    (void)f32;
+    return b64 ? 64 : 32;
 }
 
 // diagnostics: the stamps of the most recent PF_STAMP launch (8 u64 per workgroup: start, A done, barrier 1 passed, B done,

@@ -248,7 +248,11 @@ def exchange_halos(engine, group=None):
             engine.pack_halo(ix + dx, iy + dy, dx, dy, sbuf[off:off + n])
             off += n
     if world > 1:
+        if sbuf.is_cuda:
+            torch.cuda.synchronize()              # the engine packed on its own stream; the collective runs on torch's
         dist.all_to_all_single(rbuf[:sum(recv_sizes)], sbuf[:sum(send_sizes)], recv_sizes, send_sizes, group=group)
+        if rbuf.is_cuda:
+            torch.cuda.synchronize()              # ... and the engine reads rbuf on its own stream: the bytes must have landed
     halos = {}
     off = 0
     for p in range(world):
@@ -282,6 +286,8 @@ def gather_tiles(engine, dst_engine=None, root=0, group=None):
         for k, (ix, iy) in enumerate(mine):
             engine.export_tile(ix, iy, buf[k * nb:(k + 1) * nb])
         if len(mine):
+            if buf.is_cuda:
+                torch.cuda.synchronize()
             dist.send(buf[:nb * len(mine)], dst=root, group=group)
         return 0
     n = 0
@@ -293,6 +299,8 @@ def gather_tiles(engine, dst_engine=None, root=0, group=None):
             continue
         buf = engine.empty(nb * len(theirs))
         dist.recv(buf[:nb * len(theirs)], src=p, group=group)
+        if buf.is_cuda:
+            torch.cuda.synchronize()              # import_tile reads buf on the engine's stream
         for k, (ix, iy) in enumerate(theirs):
             (dst_engine or engine).import_tile(ix, iy, buf[k * nb:(k + 1) * nb])
             n += 1
