@@ -117,6 +117,78 @@ def test_dist_draw_and_save_ranks_as_threads(pf, orc, world, force_float, hq):
         d.close()
 
 
+def test_dist_caps_and_empty_ranks(pf, orc):
+    """a rank may take fewer tiles per call than it has changed (cap), and a rank may hold no tile at all: the providers
+    plan with the requester's cap, and the calls repeat until nothing is left"""
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam, poses, frames = workload(wl, 4)
+    world = 3
+    o = orc.OracleMap(scale=2.0)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    # cell edge 64 tiles: the whole mosaic belongs to one rank, the other two hold nothing
+    maps = [pf.Map2D.create(pf.TypeMultiBandCPU, False, scale=2.0, shard_rank=r, shard_count=world, shard_block=64) for r in range(world)]
+    for m in maps:
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    for f, p in zip(frames, poses):
+        assert o.feed(f, p)
+        for m in maps:
+            assert m.feed(f, p)
+    assert sorted(len(m.tiles()) for m in maps)[:2] == [0, 0]
+    rv = Rendezvous(world)
+    dms = [sh.DistMap(m, r, world, backend="host", exchange=rv.fn(r)) for r, m in enumerate(maps)]
+    got = [dict() for _ in range(world)]
+    err = []
+    calls = (len(o.tiles()) + 4) // 5 + 1                       # the last call finds nothing left
+
+    def rank_main(r):
+        try:
+            for _ in range(calls):                              # every rank makes the same number of collective calls
+                coords, px = dms[r].blend_changed(cap=5)
+                assert len(coords) <= 5
+                for t, im in zip(coords, px):
+                    assert t not in got[r]
+                    got[r][t] = im.copy()
+        except Exception as e:
+            err.append(e); rv.bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(180) for t in th]
+    assert not err, err
+    seen = {}
+    for g in got:
+        seen.update(g)
+    assert set(seen) == set(o.tiles()) and len(seen) > 10
+    for t, im in seen.items():
+        assert np.array_equal(im, o.blend_tile(*t)), t
+    for d in dms:
+        d.close()
+
+
+def test_rccl_loads_and_runs_with_one_rank(pf, orc):
+    """RCCL inside the library on the one GPU at hand: librccl is found, a one-rank communicator comes up, draw() and save()
+    go through pf_dist_* (no peer to exchange with) and equal the plain calls"""
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam, poses, frames = workload(wl, 4)
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, scale=2.0)
+    o = orc.OracleMap(scale=2.0)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2]) and o.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    for f, p in zip(frames, poses):
+        assert m.feed(f, p) and o.feed(f, p)
+    d = sh.DistMap(m, 0, 1, backend="nccl")
+    coords, px = d.blend_changed()
+    assert sorted(coords) == sorted(o.tiles())
+    for t, im in zip(coords, px):
+        assert np.array_equal(im, o.blend_tile(*t))
+    img, org = d.save_to_memory()
+    ref, oorg = o.save()
+    assert org == oorg and np.array_equal(img, ref)
+    st = d.stats()
+    assert st["bytes_sent"] == 0 and st["bytes_received"] == 0
+    d.close()
+
+
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
