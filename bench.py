@@ -205,6 +205,59 @@ def host_feed_rate(pf, wl, poses, prep, frames_host, force_float, frames=60):
             "note": "pageable host frames through pf_feed (36 MB H2D per keyframe inside feed)"}
 
 
+def run_with_deadline(fn, seconds):
+    """Run a leg that contains collectives in a thread; a leg that has not returned in time is abandoned (its record says
+    so, and the process then leaves through os._exit after printing its line: a peer stuck in a collective must not cost
+    the measurement already taken).  Returns (record, abandoned)."""
+    import threading
+    box = {}
+
+    def body():
+        box["r"] = guarded(fn)
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return {"error": "no result within %d s (a rank stuck in a collective?)" % seconds}, True
+    return box.get("r"), False
+
+
+def strong_probe(pf, wl, torch, dist, rank, N, dev, frames, base, W, K, scale, force_float, extra, backend):
+    """N > 1, inside the default (replicas) run: the SAME sortie sharded over the ranks by tile (BASELINE.json configs[2]) --
+    every rank is fed every keyframe and renders the tiles it owns; then the seam exchange of the library, timed.
+    Collective.  Rank 0 returns the record."""
+    torch.cuda.set_device(dev)
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    block, Kp, Wp = 8, min(K, 60), min(W, 10)
+    opt = pf.default_options(force_float=force_float, scale=scale, device=dev, shard_rank=rank, shard_count=N, shard_block=block, **extra)
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, options=opt)
+    ok = bool(m.prepare(wl.IDENTITY_PLANE, CAM, base[:20]))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        raise RuntimeError("prepare failed on some rank")
+    m.reserve_tiles(2600 // N + 400)
+
+    def run(lo, hi):
+        for k in range(lo, hi):
+            assert m.feed_device(frames[k % len(frames)].data_ptr(), 3000, 4000, pose_at(base, k))
+    run(0, Wp); m.sync()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(Wp, Wp + Kp); m.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rec = sh.strong_report(m, rank, N, backend)
+    m.close()
+    if rank != 0:
+        return None
+    out = {"scaling": "strong", "value": round(Kp / float(t.item()), 3), "unit": "keyframes/s", "steps": Kp, "warmup": Wp,
+           "tile_sharding": "one sortie, tiles split by spatial hash, cell %d tiles; every rank fed every keyframe" % block}
+    out.update(rec or {})
+    return out
+
+
 # ------------------------------------------------------------------------------ GPU legs
 def timed_run(m, run, W, K, event_every, barrier):
     """W untimed steps with every kernel timed (finds the dominant kernel), then K timed steps with HIP events
@@ -270,6 +323,7 @@ def main():
     ap.add_argument("--event-every", type=int, default=None,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
                          "(default steps//8; each event pair costs stream time; 0 = none, no roofline)")
+    ap.add_argument("--no-strong-probe", action="store_true", help="N > 1, --shard weak: skip the tile-sharded sub-measurement")
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 2)")
     args = ap.parse_args()
@@ -431,6 +485,14 @@ def main():
         if rank == 0:
             out["sharding"] = info
 
+    # ... and in the default (replicas) run of N > 1: the same sortie sharded by tile, with the library's seam exchange
+    abandoned = False
+    if N > 1 and not strong and not args.no_strong_probe:
+        rec, abandoned = run_with_deadline(lambda: strong_probe(pf, wl, torch, dist, rank, N, dev, frames, base, W, K, args.scale, force_float,
+                                                                extra, os.environ.get("PF_DIST_BACKEND", "nccl")), 150)
+        if rank == 0:
+            out["strong"] = rec
+
     if rank == 0:
         # measured HBM ceiling on this box: a 1 GiB device-to-device copy, read + write bytes
         def copy_ceiling():
@@ -472,6 +534,8 @@ def main():
                 out["map2dcpu_single_band"] = guarded(map2dcpu_rates, pf, wl, my_sortie, prep, frames, hostf)
     if rank == 0:
         real_out.write(json.dumps(out) + "\n"); real_out.flush()
+    if abandoned:
+        os._exit(0)                       # a peer may sit in a collective for ever: the line is out, leave without the teardown
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
