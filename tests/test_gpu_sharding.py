@@ -122,3 +122,25 @@ def test_shard_regions_not_tile_aligned(pf, force_float):
     for m in shards:
         got.update(map_digest(m))
     assert got == map_digest(ref)
+
+
+@pytest.mark.parametrize("n,block,bands,force_float", [(5, 2, 5, 0), (8, 4, 3, 1), (3, 8, 7, 0), (7, 1, 7, 1), (4, 3, 1, 0)])
+def test_need_masks_over_ranks_cells_and_bands(pf, n, block, bands, force_float):
+    """The per-block need masks of a shard (which 64x32 blocks of each level anything owned depends on) for odd rank
+    counts, cell sizes and band counts, on canvases many cells wide: the shards still partition the unsharded mosaic
+    bit for bit, and none of them renders the whole canvas."""
+    wl = workloads()
+    cam = [1600, 1200, 1100, 1100, 800, 600]
+    poses = jitter_poses(5, seed=53 + n, step=(45.0, 28.0), yaw_deg=20, height=120.0)
+    frames = [wl.noise_frame(1200, 1600, 900 + k) for k in range(len(poses))]
+    (ref,) = build(pf, cam, poses, frames, 1, 1, force_float, band_number=bands, scale=1.5)
+    shards = build(pf, cam, poses, frames, n, block, force_float, band_number=bands, scale=1.5)
+    got = {}
+    for m in shards:
+        d = map_digest(m)
+        assert not (set(d) & set(got))
+        got.update(d)
+    assert got == map_digest(ref) and len(ref.tiles()) >= 60
+    if bands >= 3 and block >= 2 and n >= 3:
+        rs = [m.render_stats() for m in shards if m.tiles()]
+        assert min(r["level0_px"] / r["owned_px"] for r in rs) < 0.9 * n      # masks at work: less than the whole canvas each
