@@ -1,0 +1,135 @@
+"""Steady state of the pipelined path (pf_options.fused = 1): runs long enough for every ring of the host
+engine to wrap several times -- the per-frame tile tables (64 slots), the shard need-masks, the staging slots
+of host frames (max_queue + 4) and the GW buffer parity -- compared with the CPU oracle tile by tile.
+bench.py times exactly this regime (frames 20..220 of a sortie), so this is the parity evidence of the
+headline number.  Reference semantics: Map2DFusion/MultiBandMap2DCPU.cpp:476-555 (Apply: ties go to the newest
+frame, a fresh tile level is copied unconditionally), :288-309 (feed), :606-635 (render thread)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from helpers import compare_maps, map_digest, workloads
+
+pytestmark = pytest.mark.gpu
+
+CAM = [640, 480, 500, 500, 320, 240]
+N_LONG = 168          # > 2 * 64 (table ring) + 5 levels in flight
+
+
+def sortie(n, seed=11):
+    """640x480 serpentine flown again and again over a 3-row area: bounded tile count, every frame a full render
+    with its own yaw / tilt, heavy overlap (the max-weight select is exercised on every pixel)."""
+    wl = workloads()
+    return wl.serpentine(CAM, 100.0, n, per_row=9, fwd_overlap=0.7, side_overlap=0.5, seed=seed,
+                         yaw_jitter_deg=12.0, tilt_jitter_deg=4.0, max_rows=3)
+
+
+def frame(k):
+    wl = workloads()
+    return wl.noise_frame(480, 640, 7000 + k % 23) if k % 3 else wl.smooth_frame(480, 640, k) ^ wl.noise_frame(480, 640, k % 5)
+
+
+def oracle_run(orc, poses, force_float, n_prepare=12, **opt):
+    wl = workloads()
+    o = orc.OracleMap(band_num=opt.get("band_number", 5), force_float=force_float)
+    assert o.prepare(wl.IDENTITY_PLANE, CAM, poses[:n_prepare])
+    for k, p in enumerate(poses):
+        assert o.feed(frame(k), p)
+    return o
+
+
+def gpu_run(pf, poses, force_float, thread=False, n_prepare=12, **opt):
+    wl = workloads()
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, thread, force_float=force_float, fused=1, **opt)
+    # thread=True renders the prepare frames first when they carry images (Map2D.cpp:42); none are given here
+    assert g.prepare(wl.IDENTITY_PLANE, CAM, poses[:n_prepare])
+    for k, p in enumerate(poses):
+        if thread:
+            # the reference's producer loop (Map2DFusion.cpp:309-327) waits while the queue is long: nothing is dropped
+            t0 = time.time()
+            while g.queueSize() >= 8:
+                time.sleep(0.0005)
+                assert time.time() - t0 < 30
+        assert g.feed(frame(k), p)
+    assert g.sync()
+    if thread:
+        assert g.stats()["dropped"] == 0
+    assert g.stats()["rendered"] == len(poses)
+    return g
+
+
+@pytest.mark.parametrize("thread", [False, True])
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_long_run_equals_oracle(pf, orc, force_float, thread):
+    """168 host frames through the pipelined path: table ring wraps twice, frame-slot ring seven times."""
+    poses = sortie(N_LONG)
+    o = oracle_run(orc, poses, force_float)
+    g = gpu_run(pf, poses, force_float, thread=thread)
+    assert g.grid() == o.grid()
+    assert compare_maps(g, o) == []
+    # blend of a few tiles after the long run (Ele::blend reads what the pipeline wrote last)
+    for (ix, iy) in o.tiles()[:6]:
+        assert np.array_equal(g.blend_tile(ix, iy), o.blend_tile(ix, iy))
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_long_run_three_shards_equal_oracle(pf, orc, force_float):
+    """Three shard maps on one card, 80 frames each: the per-frame need-mask ring (64 slots) wraps; the union of the
+    shards' tiles is the oracle's map."""
+    poses = sortie(80, seed=5)
+    o = oracle_run(orc, poses, force_float)
+    want = map_digest(o)
+    got = {}
+    for r in range(3):
+        g = gpu_run(pf, poses, force_float, shard_rank=r, shard_count=3, shard_block=1)
+        for (ix, iy) in g.tiles():
+            assert pf.tile_owner(g.opt, ix, iy) == r
+        d = map_digest(g)
+        assert not (set(d) & set(got))
+        got.update(d)
+        assert g.grid() == o.grid()
+        g.close()
+    assert got == want
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_table_copy_twin(pf, force_float):
+    """The same long run with PF_TABLE_COPY=1 (tile tables copied to HBM in the stream, the round-1 form): digests
+    must equal the default table path's."""
+    poses = sortie(N_LONG, seed=3)
+    a = map_digest(gpu_run(pf, poses, force_float))
+    os.environ["PF_TABLE_COPY"] = "1"
+    try:
+        b = map_digest(gpu_run(pf, poses, force_float))
+    finally:
+        del os.environ["PF_TABLE_COPY"]
+    assert a == b
+
+
+def test_bench_sortie_pipelined_equals_per_op(pf):
+    """bench.py's cfg-A sortie (4000x3000, 225 keyframes resident in HBM): the pipelined path (fused=1, the one
+    the headline is timed on) and the one-kernel-per-reference-op path (fused=0, oracle-checked at small sizes
+    and on 4000x3000 frames in test_gpu_at_size.py) must build the same map, tile for tile."""
+    torch = pytest.importorskip("torch")
+    wl = workloads()
+    cam = [4000, 3000, 3000, 3000, 2000, 1500]
+    n = 225
+    poses = wl.serpentine(cam, 100.0, n, max_rows=16)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1234)
+    frames = [torch.randint(0, 256, (3000, 4000, 3), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(4)]
+    torch.cuda.synchronize()
+    digests = []
+    for fused in (1, 0):
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, fused=fused)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+        for k, p in enumerate(poses):
+            assert m.feed_device(frames[k % 4].data_ptr(), 3000, 4000, p)
+        assert m.sync()
+        assert m.stats()["rendered"] == n
+        digests.append(map_digest(m))
+        m.close()
+        del m
+    assert len(digests[0]) > 1000 * 6
+    assert digests[0] == digests[1]
