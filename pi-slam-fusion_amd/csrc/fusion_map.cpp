@@ -106,7 +106,7 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     if (single_band_) { lay_.f32 = 0; lay_.lap_off[0] = 0; lay_.w_off[0] = 0; lay_.slot_bytes = kElePixels * kElePixels * 4; }
     store_.configure(lay_.slot_bytes);
     if (opt_.max_queue <= 0) opt_.max_queue = 20;
-    table_zero_copy_ = std::getenv("PF_TABLE_COPY") == nullptr;        // PF_TABLE_COPY=1: the round-1 form (H2D copy per keyframe), for A/B
+    table_in_args_ = std::getenv("PF_TABLE_COPY") == nullptr;          // PF_TABLE_COPY=1: every tile table staged and copied in the stream (A/B, tests)
     if (opt_.shard_count < 1) opt_.shard_count = 1;
     if (opt_.shard_block < 1) opt_.shard_block = 8;
 
@@ -150,7 +150,6 @@ FusionMap::~FusionMap()
     for (auto& s : slots_) { if (s.dev) (void)hipFree(s.dev); if (s.consumed) (void)hipEventDestroy(s.consumed); }
     for (int i = 0; i < kTableRing; i++) {
         if (table_host_[i]) (void)hipHostFree(table_host_[i]);
-        if (mask_host_[i]) (void)hipHostFree(mask_host_[i]);
         table_dev_[i].release();
         if (table_ev_[i]) (void)hipEventDestroy(table_ev_[i]);
         if (i < kMarks && mark_ev_[i]) (void)hipEventDestroy(mark_ev_[i]);
@@ -556,22 +555,48 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     const int tx = xmaxInt - xminInt, ty = ymaxInt - yminInt, L = band_num_;
     const int crows = ty * kElePixels, ccols = tx * kElePixels;
 
-    // tiles this shard owns inside the canvas
-    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0;
-    for (int y = 0; y < ty; y++)
-        for (int x = 0; x < tx; x++)
-            if (tile_owner(opt_.shard_count, opt_.shard_block, xminInt + x + off_x_, yminInt + y + off_y_) == opt_.shard_rank) {
+    // One pass over the canvas tiles (Apply's tile loop, .cpp:478-492): the tiles this shard owns, their bounding box,
+    // the hash cells they fall in (for the need rectangles below) and the table entries: slot address | fresh bit.
+    // The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
+    const bool sharded = opt_.shard_count > 1;
+    struct Cell { int cx, cy, x0, y0, x1, y1; };
+    Cell cells[64]; int ncells = 0; bool cells_overflow = false;
+    const int B = opt_.shard_block;
+    table_tmp_.resize((size_t)tx * ty);
+    std::vector<Tile*> touched;
+    touched.reserve((size_t)tx * ty);
+    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0;
+    for (int y = 0; y < ty; y++) {
+        const int sy = yminInt + y + off_y_;
+        for (int x = 0; x < tx; x++) {
+            const int sx = xminInt + x + off_x_;
+            uint64_t ent = 0;
+            if (!sharded || tile_owner(opt_.shard_count, B, sx, sy) == opt_.shard_rank) {
+                Tile* t = store_.get_or_create(sx, sy);
+                if (!t) return false;
+                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
+                touched.push_back(t);
+                owned++;
                 bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
+                if (sharded && !cells_overflow) {
+                    const int cx = floordiv(sx, B), cy = floordiv(sy, B);
+                    int k = ncells - 1;
+                    while (k >= 0 && !(cells[k].cx == cx && cells[k].cy == cy)) k--;
+                    if (k < 0) {
+                        if (ncells == 64) cells_overflow = true;
+                        else cells[ncells++] = Cell{ cx, cy, x, y, x + 1, y + 1 };
+                    } else {
+                        Cell& c = cells[k];
+                        c.x0 = std::min(c.x0, x); c.y0 = std::min(c.y0, y); c.x1 = std::max(c.x1, x + 1); c.y1 = std::max(c.y1, y + 1);
+                    }
+                }
             }
-    if (bx0 >= bx1) return true;                // nothing of this frame lands on this shard
-    {   // what this rank renders beyond its share (bench --shard strong): owned tile pixels vs the level-0 window
-        int owned = 0;
-        for (int y = 0; y < ty; y++)
-            for (int x = 0; x < tx; x++)
-                owned += tile_owner(opt_.shard_count, opt_.shard_block, xminInt + x + off_x_, yminInt + y + off_y_) == opt_.shard_rank;
-        px_owned_ += (double)owned * kElePixels * kElePixels;
-        n_with_pixels_++;
+            table_tmp_[(size_t)y * tx + x] = ent;
+        }
     }
+    if (bx0 >= bx1) return true;                // nothing of this frame lands on this shard
+    px_owned_ += (double)owned * kElePixels * kElePixels;     // what this rank renders beyond its share: owned tile pixels vs the level-0 window (bench --shard strong)
+    n_with_pixels_++;
 
     // per-level windows: Gaussian level i must be valid on need[i] so that the
     // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
@@ -616,38 +641,24 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             table_cap_ = (size_t)tx * ty * 2;
             for (int i = 0; i < kTableRing; i++) {
                 if (table_host_[i]) (void)hipHostFree(table_host_[i]);
-                // Host memory the kernels read in place (no copy in the stream between two dependent launches): non-coherent
-                // = cacheable in the GPU's L2, made visible at kernel boundaries, so a table of a few hundred entries
-                // costs a few dozen PCIe reads per XCD and launch.
-                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, table_zero_copy_ ? hipHostMallocNonCoherent : hipHostMallocDefault));
-                table_ptr_[i] = table_host_[i];
-                if (table_zero_copy_) HIP_OK(hipHostGetDevicePointer((void**)&table_ptr_[i], table_host_[i], 0));
-                else { if (!table_dev_[i].reserve(table_cap_ * 8)) return false; table_ptr_[i] = (uint64_t*)table_dev_[i].p; }
+                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, hipHostMallocDefault));
+                if (!table_dev_[i].reserve(table_cap_ * 8)) return false;
                 table_pending_[i] = false;
             }
         }
     }
 
-    // tile table (Apply's tile loop, .cpp:478-492): slot address | fresh bit
+    // the frame's tile table -> ring slot in device memory
     const int ring = (int)(frame_seq_++ % kTableRing);
     if (table_pending_[ring]) { HIP_OK(hipEventSynchronize(table_ev_[ring])); table_pending_[ring] = false; }
-    if (!wait_for(table_release_[ring])) return false;
-    uint64_t* tab = table_host_[ring];
-    std::vector<Tile*> touched;
-    for (int y = 0; y < ty; y++)
-        for (int x = 0; x < tx; x++) {
-            const int sx = xminInt + x + off_x_, sy = yminInt + y + off_y_;
-            uint64_t ent = 0;
-            if (tile_owner(opt_.shard_count, opt_.shard_block, sx, sy) == opt_.shard_rank) {
-                Tile* t = store_.get_or_create(sx, sy);
-                if (!t) return false;
-                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
-                touched.push_back(t);
-            }
-            tab[y * tx + x] = ent;
-        }
-    if (!table_zero_copy_) HIP_OK(hipMemcpyAsync(table_dev_[ring].p, tab, (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
-    const uint64_t* dtab = table_ptr_[ring];
+    const bool table_args = table_in_args_ && opt_.fused == 1 && !single_band_ && L >= 2 && (size_t)tx * ty <= (size_t)kArgTable;
+    if (!table_args) {
+        // staged in pinned memory and copied in the stream; the staging slot is reused once that copy has run
+        if (!wait_for(table_release_[ring])) return false;
+        std::memcpy(table_host_[ring], table_tmp_.data(), (size_t)tx * ty * 8);
+        HIP_OK(hipMemcpyAsync(table_dev_[ring].p, table_host_[ring], (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
+    }
+    const uint64_t* dtab = (const uint64_t*)table_dev_[ring].p;
 
     // warp (.cpp:443-452)
     WarpArgs a{};
@@ -695,52 +706,25 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             clampw(y0, y1, rows, C[i].y0, C[i].y1);
         }
         const double E = 3 * es + 4;
-        // A shard's tiles are scattered hash cells, and the compute regions above are their bounding box: mark the 64x32
-        // blocks that something owned depends on, per level, with the same recursion applied per cell -- the others exit at
-        // once.  (Unsharded: every block is needed, no mask.)
-        const uint8_t* masks[kMaxLevels] = {};
-        double owned_tiles = (double)(bx1 - bx0) * (by1 - by0), blocks_run0 = 0;
-        if (opt_.shard_count > 1 && opt_.fused == 1) {
-            struct Cell { int x0, y0, x1, y1; };
+        // A shard's tiles are scattered hash cells, and the compute regions above are their bounding box: per level, one
+        // rectangle of 64x32 blocks per cell says where something owned depends on a block (the same recursion as `need`,
+        // applied per cell); blocks outside every rectangle exit at once.  (Unsharded: every block is needed, no rectangles.)
+        BlockRect rects[kMaxLevels][kMaxRects];
+        int nrect[kMaxLevels] = {};
+        double owned_tiles = owned, blocks_run0 = 0;
+        if (sharded && opt_.fused == 1 && !cells_overflow) {
             const int BHr = level_block_rows(lay_.f32 != 0);
-            std::unordered_map<uint64_t, Cell> cells;
-            const int B = opt_.shard_block;
-            owned_tiles = 0;
-            for (int y = 0; y < ty; y++)
-                for (int x = 0; x < tx; x++) {
-                    const int sx = xminInt + x + off_x_, sy = yminInt + y + off_y_;
-                    if (tile_owner(opt_.shard_count, B, sx, sy) != opt_.shard_rank) continue;
-                    owned_tiles++;
-                    const uint64_t key = ((uint64_t)(uint32_t)floordiv(sx, B) << 32) | (uint32_t)floordiv(sy, B);
-                    auto it = cells.find(key);
-                    if (it == cells.end()) cells.emplace(key, Cell{ x, y, x + 1, y + 1 });
-                    else { Cell& c = it->second; c.x0 = std::min(c.x0, x); c.y0 = std::min(c.y0, y); c.x1 = std::max(c.x1, x + 1); c.y1 = std::max(c.y1, y + 1); }
-                }
-            size_t need_bytes = 0, off[kMaxLevels];
-            int nbx[kMaxLevels], nby[kMaxLevels];
-            for (int i = 0; i < L; i++) {
-                nbx[i] = (C[i].x1 - C[i].x0 + 63) / 64; nby[i] = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
-                off[i] = need_bytes; need_bytes += ((size_t)std::max(nbx[i], 0) * std::max(nby[i], 0) + 63) / 64 * 64;
-            }
-            if (mask_cap_ < need_bytes) {
-                HIP_OK(sync_all());
-                mask_cap_ = need_bytes * 2;
-                for (int k = 0; k < kTableRing; k++) {
-                    if (mask_host_[k]) (void)hipHostFree(mask_host_[k]);
-                    HIP_OK(hipHostMalloc((void**)&mask_host_[k], mask_cap_, hipHostMallocNonCoherent));
-                    HIP_OK(hipHostGetDevicePointer((void**)&mask_ptr_[k], mask_host_[k], 0));
-                }
-            }
-            uint8_t* mk = mask_host_[ring];
-            std::memset(mk, 0, need_bytes);
-            for (auto& kv : cells) {
+            struct R { int x0, y0, x1, y1; };
+            std::vector<R> lv[kMaxLevels];
+            for (int c = 0; c < ncells; c++) {
                 // N[i]: where Gaussian level i is needed for this cell's tiles (pixel-exact: pyrDown reads [2p-2, 2p+2],
-                // pyrUp +-1 -- the recursion of `need` above, per cell).  The level-i block at b runs iff it holds owned
-                // pixels or its part of level i+1 lies in N[i+1]; what else it computes from unproduced input is never read.
+                // pyrUp +-1).  The level-i block at b runs iff it holds owned pixels or its part of level i+1 lies in
+                // N[i+1]; what else it computes from unproduced input is never read.
+                const Cell& ce = cells[c];
                 Win N[kMaxLevels];
                 for (int i = L; i >= 0; i--) {
                     const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
-                    int x0 = kv.second.x0 * ts, x1 = kv.second.x1 * ts, y0 = kv.second.y0 * ts, y1 = kv.second.y1 * ts;
+                    int x0 = ce.x0 * ts, x1 = ce.x1 * ts, y0 = ce.y0 * ts, y1 = ce.y1 * ts;
                     if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
                     if (i < L) {
                         x0 = std::min(x0, 2 * N[i + 1].x0 - 2); x1 = std::max(x1, 2 * N[i + 1].x1 + 1);
@@ -751,16 +735,41 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 }
                 for (int i = 0; i < L; i++) {
                     const int ts = kElePixels >> i;
-                    int x0 = std::min(kv.second.x0 * ts, 2 * N[i + 1].x0), x1 = std::max(kv.second.x1 * ts, 2 * N[i + 1].x1);
-                    int y0 = std::min(kv.second.y0 * ts, 2 * N[i + 1].y0), y1 = std::max(kv.second.y1 * ts, 2 * N[i + 1].y1);
+                    int x0 = std::min(ce.x0 * ts, 2 * N[i + 1].x0), x1 = std::max(ce.x1 * ts, 2 * N[i + 1].x1);
+                    int y0 = std::min(ce.y0 * ts, 2 * N[i + 1].y0), y1 = std::max(ce.y1 * ts, 2 * N[i + 1].y1);
                     x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
                     if (x0 >= x1 || y0 >= y1) continue;
-                    const int gx0 = (x0 - C[i].x0) / 64, gy0 = (y0 - C[i].y0) / BHr, gx1 = (x1 - C[i].x0 + 63) / 64, gy1 = (y1 - C[i].y0 + BHr - 1) / BHr;
-                    for (int gy = gy0; gy < gy1; gy++) std::memset(mk + off[i] + (size_t)gy * nbx[i] + gx0, 1, (size_t)(gx1 - gx0));
+                    lv[i].push_back(R{ (x0 - C[i].x0) / 64, (y0 - C[i].y0) / BHr, (x1 - C[i].x0 + 63) / 64, (y1 - C[i].y0 + BHr - 1) / BHr });
                 }
             }
-            for (int i = 0; i < L; i++) masks[i] = mask_ptr_[ring] + off[i];
-            for (size_t k = 0; k < (size_t)nbx[0] * nby[0]; k++) blocks_run0 += mk[off[0] + k];
+            for (int i = 0; i < L; i++) {
+                // at most kMaxRects travel with a job: merge the pair whose common bounding box adds the fewest blocks
+                // (extra blocks only cost time: they hold no owned pixel and write no tile)
+                std::vector<R>& v = lv[i];
+                auto area = [](const R& r) { return (long)(r.x1 - r.x0) * (r.y1 - r.y0); };
+                while ((int)v.size() > kMaxRects) {
+                    size_t ba = 0, bb = 1; long best = -1;
+                    for (size_t p = 0; p < v.size(); p++)
+                        for (size_t q = p + 1; q < v.size(); q++) {
+                            const R u{ std::min(v[p].x0, v[q].x0), std::min(v[p].y0, v[q].y0), std::max(v[p].x1, v[q].x1), std::max(v[p].y1, v[q].y1) };
+                            const long add = area(u) - area(v[p]) - area(v[q]);
+                            if (best < 0 || add < best) { best = add; ba = p; bb = q; }
+                        }
+                    v[ba] = R{ std::min(v[ba].x0, v[bb].x0), std::min(v[ba].y0, v[bb].y0), std::max(v[ba].x1, v[bb].x1), std::max(v[ba].y1, v[bb].y1) };
+                    v.erase(v.begin() + bb);
+                }
+                nrect[i] = (int)v.size();
+                for (int k = 0; k < nrect[i]; k++) rects[i][k] = BlockRect{ (short)v[k].x0, (short)v[k].y0, (short)v[k].x1, (short)v[k].y1 };
+                if (v.empty()) { nrect[i] = 1; rects[i][0] = BlockRect{ 0, 0, 0, 0 }; }      // nothing needed at this level: an empty rectangle
+            }
+            {   // level-0 blocks that run (render_stats, bench --shard strong)
+                const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+                block_bits_.assign((size_t)std::max(nbx, 0) * std::max(nby, 0), 0);
+                for (int k = 0; k < nrect[0]; k++)
+                    for (int gy = rects[0][k].y0; gy < rects[0][k].y1; gy++)
+                        if (rects[0][k].x1 > rects[0][k].x0) std::memset(block_bits_.data() + (size_t)gy * nbx + rects[0][k].x0, 1, (size_t)(rects[0][k].x1 - rects[0][k].x0));
+                for (uint8_t v : block_bits_) blocks_run0 += v;
+            }
             px_level0_ += blocks_run0 * 64 * BHr;
         } else
             px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
@@ -769,11 +778,13 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             PipeFrame cur;
             cur.valid = true; cur.ring = ring; cur.tx = tx; cur.crows = crows; cur.ccols = ccols;
             for (int i = 0; i < L; i++) {
-                cur.C[i] = C[i]; cur.mask[i] = masks[i];
+                cur.C[i] = C[i]; cur.nrect[i] = nrect[i];
+                for (int k = 0; k < nrect[i]; k++) cur.rect[i][k] = rects[i][k];
                 const double ts = kElePixels >> i, n = owned_tiles * ts * ts;
                 // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
                 cur.bytes[i] = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0) + (i == 0 ? (double)a.src_cn * f.rows * f.cols : 0);
             }
+            if (table_args) { cur.table_args = table_tmp_.data(); cur.table_n = tx * ty; }
             if (!launch_pipeline(&cur, &a, src)) return false;
         } else {
         // fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
@@ -903,7 +914,10 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.cx0 = fr.C[i].x0; q.cy0 = fr.C[i].y0; q.cx1 = fr.C[i].x1; q.cy1 = fr.C[i].y1;
         q.tiles_x = fr.tx; q.top_select = top; q.write_next = !top; q.from_warp = (i == 0);
         q.gw_in = i == 0 ? nullptr : in[i].p; q.gw_out = top ? nullptr : out[i + 1].p;
-        q.table = table_ptr_[fr.ring]; q.mask = fr.mask[i];
+        q.table = (const uint64_t*)table_dev_[fr.ring].p;
+        q.table_args = i == 0 ? fr.table_args : nullptr; q.table_n = i == 0 ? fr.table_n : 0;
+        q.nrect = fr.nrect[i];
+        for (int k = 0; k < fr.nrect[i]; k++) q.rect[k] = fr.rect[i][k];
         bytes += fr.bytes[i];
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid

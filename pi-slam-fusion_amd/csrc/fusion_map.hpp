@@ -162,13 +162,15 @@ private:
     hipEvent_t  lvl_ev_[kMaxLevels][kLvlRing]{};    // fused = 2/3: level i of the frame in ring slot k has run
     hipStream_t prof_stream_ = nullptr;
     static constexpr int kUpperStreams = 1;         // streams shared by pyramid levels >= 1
-    uint64_t*  table_host_[kTableRing]{};
-    uint8_t*   mask_host_[kTableRing]{};            // per-frame block masks of a shard (pinned, read in place like the tables)
-    uint8_t*   mask_ptr_[kTableRing]{};
-    size_t     mask_cap_ = 0;
-    uint64_t*  table_ptr_[kTableRing]{};            // what the kernels dereference: the host table itself (zero copy) or table_dev_
-    bool       table_zero_copy_ = true;
+    // Tile tables live in device memory (table_dev_, a ring of kTableRing per-frame tables).  How a frame's table gets
+    // there: inside the kernel arguments of the launch that carries the frame's level 0, which stores it to the ring slot
+    // itself (pipelined path, tables of at most kArgTable entries: nothing sits in the stream between two launches and
+    // no host memory is read in place); otherwise staged in pinned host memory and copied in the stream.
+    uint64_t*  table_host_[kTableRing]{};           // pinned staging of the copy path
+    bool       table_in_args_ = true;               // PF_TABLE_COPY=1 forces the copy path (A/B, tests)
     DevBuf     table_dev_[kTableRing];
+    std::vector<uint64_t> table_tmp_;               // a frame's entries while they are being built
+    std::vector<uint8_t>  block_bits_;              // level-0 blocks a shard runs (render_stats only)
     size_t     table_cap_ = 0;
     hipEvent_t table_ev_[kTableRing]{};             // fused = 2/3: last reader of the ring slot done (own stream)
     bool       table_pending_[kTableRing]{};
@@ -188,7 +190,9 @@ private:
 
     // pipelined level launches (opt_.fused == 1): pipe_[s] is the frame whose level s runs in the next launch
     struct Win { int x0, x1, y0, y1; };
-    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels]; const uint8_t* mask[kMaxLevels]; };
+    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels];
+                       int nrect[kMaxLevels]; BlockRect rect[kMaxLevels][kMaxRects];        // LevelLaunch::rect of each level
+                       const uint64_t* table_args = nullptr; int table_n = 0; };            // level 0 only, valid during render_frame
     PipeFrame pipe_[kMaxLevels];
     unsigned long long launch_seq_ = 0;             // parity selects the GW buffer set a launch writes
     bool flushing_ = false;

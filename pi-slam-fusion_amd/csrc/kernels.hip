@@ -314,6 +314,12 @@ struct FusedWarp {
     int    plain;           // host-checked: |M| entries < 2^400 and the frame is at most 32767 px on a side, so W
                             // cannot leave the mid range upwards and saturate_cast<short> never alters an
                             // in-frame coordinate (0: every pixel takes the general forms)
+    // LDS-staged source patch (k_levels<..., PATCH = true>, see patch_plan): a level-0 block stages the part of the frame
+    // and of the weight plane its 71x39 warped pixels read -- source rectangle [c - h, c + h + 1] around the image c of the
+    // block's centre -- with coalesced 16-byte loads; the bilinear taps and the weight then come from LDS.
+    float  Mf[9];           // M in fp32: only places the patch (a pixel outside it takes the global-memory path)
+    int    phx, phy;        // half extents of the patch, source pixels
+    int    pitch_i, pitch_w;// LDS row pitches of the frame patch and of the weight patch, bytes (multiples of 16)
 };
 
 struct LevelArgs {
@@ -504,8 +510,8 @@ __device__ __forceinline__ WT up_h_val(WT a, WT b, WT c, bool odd, bool le, bool
 }
 
 // max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
-template <bool F32>
-__device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, int level, const uint64_t* __restrict__ table, int tiles_x,
+template <bool F32, typename TablePtr>
+__device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, int level, TablePtr table, int tiles_x,
                                              int x, int y, const typename Pix<F32>::T v[3], float sw)
 {
     using T = typename Pix<F32>::T;
@@ -784,12 +790,20 @@ __device__ __forceinline__ void phase_stamp(unsigned long long* st, int slot)
     }
 }
 
-template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2>
+// bytes of LDS a PATCH workgroup has behind A for the source patch (Bt lives there after stage A): two workgroups per CU
+constexpr int kPatchBytes = 81920 - 44928;
+
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false>
 __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
                                              const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
-                                             PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table, const int b,
-                                             unsigned long long* stamps = nullptr)
+                                             PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table_generic, const int b,
+                                             unsigned long long* stamps = nullptr, const uint64_t* tab0 = nullptr)
 {
+    // tab0 (level-0 job of a pipelined launch): the same table inside the kernel arguments -- the copy in device memory is
+    // written by this very launch, for the later ones.  Only the quad's entry is read from it (the top-level select of
+    // stage B belongs to the last level job, which is never the job of the newest frame when there are two levels or more).
+    // the table lies in device memory or in the kernel-argument segment: global memory either way (not a FLAT access)
+    const uint64_t PF_GLOBAL* __restrict__ table = (const uint64_t PF_GLOBAL*)table_generic;
     if (STAMP) phase_stamp(stamps, 0);
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
@@ -799,12 +813,18 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     // A is split by column parity, [row][parity][column / 2]: the pyrDown taps of neighbouring threads (2q .. 2q+4)
     // and the 2x2 quads of stage D are then 16 bytes apart per lane instead of 32 -- no LDS bank conflicts
     __shared__ Px A[LAH][2][LAWH];
-    __shared__ Bx Bt[LQH][LQW];
+    // Bt (stage B -> D) and, in a PATCH kernel, the source patch of stage A share the LDS behind A: the patch is dead at
+    // the barrier that ends stage A, Bt is first written after it
+    constexpr int kTail = PATCH ? kPatchBytes : (int)(sizeof(Bx) * LQH * LQW);
+    static_assert(kTail >= (int)(sizeof(Bx) * LQH * LQW), "Bt must fit");
+    __shared__ __attribute__((aligned(16))) unsigned char tail[kTail];
+    Bx (*Bt)[LQW] = reinterpret_cast<Bx (*)[LQW]>(tail);
     auto Aat = [&](int r, int c) -> Px& { return A[r][c & 1][c >> 1]; };
     // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
     // workgroups per CU, int16 under 32 for four
-    static_assert(LBH != 32 || sizeof(A) + sizeof(Bt) <= (F32 ? 42 : 32) * 1280, "LDS budget (64x32 blocks)");
-    static_assert(LBH != 64 || sizeof(A) + sizeof(Bt) <= (F32 ? 128 : 64) * 1280, "LDS budget (64x64 blocks of 1024 threads: int16 two per CU, fp32 one)");
+    static_assert(LBH != 32 || PATCH || sizeof(A) + sizeof(tail) <= (F32 ? 42 : 32) * 1280, "LDS budget (64x32 blocks)");
+    static_assert(LBH != 32 || !PATCH || sizeof(A) + sizeof(tail) <= 64 * 1280, "LDS budget (64x32 blocks with a source patch: two per CU)");
+    static_assert(LBH != 64 || sizeof(A) + sizeof(tail) <= (F32 ? 128 : 64) * 1280, "LDS budget (64x64 blocks of 1024 threads: int16 two per CU, fp32 one)");
 
     const int bx = b % g.nbx, by = b / g.nbx;
     const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
@@ -813,11 +833,17 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
     const int tid = threadIdx.x;
     const int sh = 8 - g.level, ts = kElePixels >> g.level;
+    if ((g.ablate & 512) && !FROM_WARP) __builtin_amdgcn_s_setprio(2);      // A/B: upper-level (latency-bound) workgroups first
 
     // this thread's output quad and its tile-table entry (a quad never straddles tiles)
     const int qx = tid & 31, qy = tid >> 5;
     const int dx0 = x0 + 2 * qx, dy0 = y0 + 2 * qy;
-    uint64_t ent = (tid < 32 * (LBH / 2) && dx0 < g.cols && dy0 < g.rows) ? table[(dy0 >> sh) * g.tiles_x + (dx0 >> sh)] : 0;
+    uint64_t ent = 0;
+    if (tid < 32 * (LBH / 2) && dx0 < g.cols && dy0 < g.rows) {
+        const int ti = (dy0 >> sh) * g.tiles_x + (dx0 >> sh);
+        if (tab0) ent = ((const uint64_t PF_GLOBAL*)tab0)[ti];
+        else ent = table[ti];
+    }
 
     // ---- A
     if (FROM_WARP) {
@@ -838,6 +864,132 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             if (!inner) y = near101 ? border_reflect101_near(y, g.rows) : border_reflect101(y, g.rows);
             return y;
         };
+        if constexpr (PATCH) {
+            // ---- the block's source patch: frame bytes and weight plane around the image of the block's centre -> LDS
+            // (placement only needs to be roughly right: a pixel whose taps fall outside takes the global-memory path)
+            const float fxc = (float)(ax0 + LAW / 2), fyc = (float)(ay0 + LAH / 2);
+            const float Wc = wa.Mf[6] * fxc + wa.Mf[7] * fyc + wa.Mf[8], iw = __builtin_amdgcn_rcpf(Wc);
+            const float pcx = (wa.Mf[0] * fxc + wa.Mf[1] * fyc + wa.Mf[2]) * iw, pcy = (wa.Mf[3] * fxc + wa.Mf[4] * fyc + wa.Mf[5]) * iw;
+            // clamp before the conversion: a wild centre gives an empty patch, not undefined behaviour
+            const int icx = (int)__builtin_floorf(fminf(fmaxf(pcx, -1.0e6f), 1.0e6f)), icy = (int)__builtin_floorf(fminf(fmaxf(pcy, -1.0e6f), 1.0e6f));
+            int px0 = __builtin_amdgcn_readfirstlane(icx) - wa.phx, py0 = __builtin_amdgcn_readfirstlane(icy) - wa.phy;
+            int px1 = px0 + 2 * wa.phx + 2, py1 = py0 + 2 * wa.phy + 2;
+            px0 = px0 > 0 ? px0 : 0; py0 = py0 > 0 ? py0 : 0;                   // clipped to the frame: inside it no tap is reflected
+            px1 = px1 < wa.scols ? px1 : wa.scols; py1 = py1 < wa.srows ? py1 : wa.srows;
+            const int pw = px1 - px0, ph = py1 - py0;                            // <= 0: no pixel of this block reads inside the frame
+            const int cn = wa.cn, pitch_i = wa.pitch_i, pitch_w = wa.pitch_w;
+            const int sb = (px0 * cn) & ~15, sbo = px0 * cn - sb;              // row bytes are staged from a 16-byte boundary of the row
+            const int wb = (px0 * 4) & ~15, swo = px0 * 4 - wb;
+            unsigned char* const pimg = tail;
+            unsigned char* const pwgt = tail + (2 * wa.phy + 2) * pitch_i;
+            if (pw > 1 && ph > 1) {
+                // one wave = one patch row per round: lanes [0, nci) the frame chunks, [nci, nci + ncw) the weight chunks
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(1)));
+                const int lane = tid & 63, wv = tid >> 6, nci = pitch_i >> 4;
+                const bool isw = lane >= nci;
+                const int ch = isw ? lane - nci : lane;
+                // only the chunks that hold bytes a tap can read: [sbo, sbo + (pw-2)*cn + 8) of a frame row, [swo, swo + pw*4) of a weight row
+                const bool on = ch * 16 < (isw ? swo + pw * 4 : sbo + (pw - 2) * cn + 8);
+                constexpr int NW = LNT / 64, UNR = 4;
+                for (int rb = wv; rb < ph; rb += NW * UNR) {
+                    u4 v[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int r = rb + u * NW;
+                        v[u] = u4{ 0, 0, 0, 0 };
+                        if (on && r < ph) {
+                            if (isw) {
+                                // the weight plane carries 64 bytes of slack behind its last row (fusion_map.cpp)
+                                const char* rowp = (const char*)(wa.wmap + (size_t)(py0 + r) * wa.scols) + wb;
+                                v[u] = *(const u4u*)(rowp + ch * 16);
+                            } else {
+                                const long off = (long)(py0 + r) * wa.sstep + sb + ch * 16;
+                                if (off + 16 <= wa.total) v[u] = *(const u4u*)(src + off);
+                                else {                                            // the last bytes of the frame: never read past them
+                                    uint32_t w4[4] = { 0, 0, 0, 0 };
+                                    for (int k = 0; k < 16; k++) if (off + k < wa.total) w4[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+                                    v[u] = u4{ w4[0], w4[1], w4[2], w4[3] };
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int r = rb + u * NW;
+                        if (on && r < ph) *(u4*)((isw ? pwgt + r * pitch_w : pimg + r * pitch_i) + ch * 16) = v[u];
+                    }
+                }
+            }
+            __syncthreads();
+            if (r0 < RS) {
+                const int x = col_of(c);
+                const WarpCol col = warp_col(wa, x);
+                const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;
+                typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+                struct Cd { int X, Y, Xn, Yn; bool ok; };
+                // a pixel takes its taps from the patch when (ux, ux+1) x (uy, uy+1) lie inside it; an empty patch takes none
+                const unsigned okw = pw > 1 && ph > 1 ? (unsigned)(pw - 1) : 0u, okh = pw > 1 && ph > 1 ? (unsigned)(ph - 1) : 0u;
+                // coordinates exactly as warp_fetch_pre's common case (the host checked that every pixel of this canvas is
+                // "tame": FusedWarp::plain == 2), then: do both taps' rows and columns lie inside the staged patch?
+                auto coords = [&](int y) {
+                    const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
+                    const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
+                    const double Wn = rcp_mid_range(W);
+                    const double pxn = xn * Wn, pyn = yn * Wn;
+                    constexpr double kMagic = 6755399441055744.0;
+                    Cd o;
+                    o.Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
+                    o.Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
+                    o.X  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn * 32. + kMagic);
+                    o.Y  = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn * 32. + kMagic);
+                    o.ok = (unsigned)((o.X >> 5) - px0) < okw && (unsigned)((o.Y >> 5) - py0) < okh;
+                    return o;
+                };
+                auto fast = [&](const Cd& q) {
+                    // taps (ux, ux+1) x (uy, uy+1) and the nearest pixel (Xn, Yn) -- one of those four -- are inside the frame
+                    const int la = __mul24((q.Y >> 5) - py0, pitch_i) + __mul24(q.X >> 5, cn) - sb;
+                    const u2 b0 = *(const u2*)(pimg + la), b1 = *(const u2*)(pimg + la + pitch_i);
+                    const float wv_ = *(const float*)(pwgt + __mul24(q.Yn - py0, pitch_w) + q.Xn * 4 - wb);
+                    PxT<F32> o;
+                    o.w = wv_;
+                    const float fx = (float)(q.X & 31) * (1.f / 32), fy = (float)(q.Y & 31) * (1.f / 32);
+                    const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
+                    const uint32_t h0 = __builtin_amdgcn_perm(b0.y, b0.x, hisel), h1 = __builtin_amdgcn_perm(b1.y, b1.x, hisel);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        float v0 = (float)((b0.x >> (8 * k)) & 0xff), v1 = (float)((h0 >> (8 * k)) & 0xff);
+                        float v2 = (float)((b1.x >> (8 * k)) & 0xff), v3 = (float)((h1 >> (8 * k)) & 0xff);
+                        if constexpr (F32) {
+                            const float sc = (float)(1. / 255.);
+                            v0 = v0 * sc; v1 = v1 * sc; v2 = v2 * sc; v3 = v3 * sc;
+                            o.c[k] = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+                        } else {
+                            // every partial sum is a multiple of 2^-10 below 2^8: exact in fp32 whatever the association, fused or not
+                            const float tt = __builtin_fmaf(v3, c3, __builtin_fmaf(v2, c2, __builtin_fmaf(v1, c1, v0 * c0)));
+                            o.c[k] = (short)sat_short(__float2int_rn(tt));
+                        }
+                    }
+                    if constexpr (!F32) o.pad = 0;
+                    return o;
+                };
+                for (int r = r0; r < LAH; r += 2 * RS) {
+                    const int rb = r + RS;
+                    const bool hasb = rb < LAH;
+                    const int y = row_of(r), yb = row_of(hasb ? rb : r);
+                    if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
+                    const Cd qa = coords(y), qb = coords(yb);
+                    if (__builtin_amdgcn_ballot_w64(!(qa.ok && qb.ok)) == 0) {
+                        Aat(r, c) = fast(qa);
+                        const PxT<F32> pb = fast(qb);
+                        if (hasb) Aat(rb, c) = pb;
+                    } else {
+                        Aat(r, c) = warp_pixel<F32>(src, wa, col, y);
+                        if (hasb) Aat(rb, c) = warp_pixel<F32>(src, wa, col, yb);
+                    }
+                }
+            }
+        } else
         if (r0 < RS) {
             const int x = col_of(c);
             const WarpCol col = warp_col(wa, x);
@@ -888,6 +1040,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     lds_barrier();
     if (STAMP) phase_stamp(stamps, 2);
     if (g.ablate & 2) return;
+    if (g.ablate & 256) __builtin_amdgcn_s_setprio(2);           // A/B: the short memory-bound stages ahead of other workgroups' warp
 
     // stored weights of the quad: in flight during stage B
     float dwv[2][2] = { { -1.f, -1.f }, { -1.f, -1.f } };           // fresh tile: every weight (>= 0) wins
@@ -1126,15 +1279,19 @@ struct LevelJob {
     LevelArgs    g;
     const void*  gw_in;
     void*        gw_out;
-    const uint64_t* table;     // the tile table of the job's frame
-    const uint8_t*  mask;      // see LevelLaunch::mask
+    const uint64_t* table;     // the tile table of the job's frame (device memory)
     int first;                 // first block id
     int from_warp;             // level 0: stage A is the warp of the launch's frame
+    int nrect;                 // see LevelLaunch::rect
+    BlockRect rect[kMaxRects];
 };
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential; LevelJob job[kMaxLevels]; };      // job[k].first, k >= 1: block offset among the upper-level jobs
+// job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
+// in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
+static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
-template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2>
-__global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false>
+__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? 6 : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
     // when there is one) or to the upper-level jobs: last in the grid by default, or (PF_INTERLEAVE_JOBS, diagnostics)
@@ -1142,7 +1299,8 @@ __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp w
     const int g = (int)blockIdx.x >> 3, lane8 = (int)blockIdx.x & 7;
     const int ug = batch.upper_groups, tg = batch.total_groups;
     int u0 = (int)(((long)g * ug) / tg), u1 = (int)(((long)(g + 1) * ug) / tg);
-    if (batch.sequential) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // diagnostics: upper levels last
+    if (batch.sequential == 1) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // upper levels last (default)
+    if (batch.sequential == 2) { u0 = g < ug ? g : ug; u1 = g < ug ? g + 1 : ug; }                             // upper levels first (PF_UPPER_FIRST)
     int j = 0, b;
     if (u1 > u0) {                                            // an upper-level group
         b = u0 * 8 + lane8;
@@ -1155,11 +1313,24 @@ __global__ __launch_bounds__(LNT, 4) void k_levels(LevelBatch batch, FusedWarp w
     const int nblk = J.g.nbx * J.g.nby;
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
     const int bb = xcd_order(b, nblk);
-    if (J.mask && !J.mask[bb]) return;                         // a shard: no tile of this rank depends on the block
+    // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
+    // carry this frame's upper levels will read it (kernel boundaries order that)
+    // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
+    const uint64_t* tab0 = nullptr;
+    if (j == 0 && batch.tab0_n) {
+        tab0 = (const uint64_t*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LevelBatch, tab0));
+        if (b == 0) for (int i = threadIdx.x; i < batch.tab0_n; i += LNT) const_cast<uint64_t*>(J.table)[i] = tab0[i];
+    }
+    if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
+        const int bx = bb % J.g.nbx, by = bb / J.g.nbx;
+        bool hit = false;
+        for (int k = 0; k < J.nrect; k++) hit = hit || (bx >= J.rect[k].x0 && bx < J.rect[k].x1 && by >= J.rect[k].y0 && by < J.rect[k].y1);
+        if (!hit) return;
+    }
     unsigned long long* st = nullptr;
     if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
-    level3_block<F32, LBH, LNT, STAMP, ILP>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                            J.table, bb, st);
+    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
+                                                   J.table, bb, st, tab0);
 }
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1169,6 +1340,57 @@ static int plain_homography(const WarpArgs& wa)
     if (force_general || wa.srows > 32767 || wa.scols > 32767) return 0;
     for (int i = 0; i < 9; i++) if (!(std::fabs(wa.M[i]) < 0x1p400)) return 0;
     return 1;
+}
+
+// Can this frame's level 0 run with LDS-staged source patches (k_levels<..., PATCH>)?  Needs, over the whole canvas plus
+// the 4-pixel halo of the blocks: W of one sign and every source coordinate far inside the int range (then no pixel
+// needs warp_fetch_pre's range test), and a patch -- the source rectangle a 71x39 block of canvas pixels maps into,
+// bounded from the map's behaviour at the canvas corners and centre, two pixels of margin -- that fits the LDS budget.
+// Fills w.Mf / phx / phy / pitch_*.  A pixel that falls outside its block's patch all the same (the bound is an estimate
+// for strongly projective maps) takes the global-memory path inside the kernel: results never depend on this plan.
+static bool patch_plan(const WarpArgs& wa, int crows, int ccols, int block_rows, FusedWarp& w)
+{
+    // Measured on MI355X (profiles/r03_patch_stage_a.md): the staged form needs 2 workgroups per CU instead of 3 and is
+    // slower than the global gather on cfg-A -- it runs on request only (PF_PATCH=1; parity-tested like the default path)
+    static const bool on = getenv("PF_PATCH") != nullptr;
+    if (!on || !w.plain || block_rows != 32) return false;
+    const double* M = wa.M;
+    auto map = [&](double x, double y, double& px, double& py, double& W) {
+        W = M[6] * x + M[7] * y + M[8];
+        px = (M[0] * x + M[1] * y + M[2]) / W; py = (M[3] * x + M[4] * y + M[5]) / W;
+    };
+    const double xs[2] = { -4.0, ccols + 3.0 }, ys[2] = { -4.0, crows + 3.0 };
+    double wmin = 0, nmax = 0; int sign = 0;
+    for (int i = 0; i < 4; i++) {
+        const double x = xs[i & 1], y = ys[i >> 1], W = M[6] * x + M[7] * y + M[8];
+        if (!(std::fabs(W) > 1e-300)) return false;
+        const int sg = W > 0 ? 1 : -1;
+        if (sign && sg != sign) return false;
+        sign = sg;
+        wmin = i ? std::min(wmin, std::fabs(W)) : std::fabs(W);
+        nmax = std::max(nmax, std::max(std::fabs(M[0] * x + M[1] * y + M[2]), std::fabs(M[3] * x + M[4] * y + M[5])));
+    }
+    // numerators and W are affine: their extremes over the rectangle are at its corners; 1e7 leaves the kernel's 3e7 a wide margin
+    if (!(nmax / wmin < 1.0e7) || !(wmin > 0x1p-400) ) return false;
+    double ex = 0, ey = 0;
+    const double cx[5] = { 32.0, ccols - 32.0, 32.0, ccols - 32.0, ccols * 0.5 }, cy[5] = { 16.0, 16.0, crows - 16.0, crows - 16.0, crows * 0.5 };
+    for (int k = 0; k < 5; k++) {
+        double p0x, p0y, W;
+        map(cx[k], cy[k], p0x, p0y, W);
+        for (int i = 0; i < 4; i++) {
+            double qx, qy;
+            map(cx[k] + ((i & 1) ? 36.0 : -36.0), cy[k] + ((i >> 1) ? 20.0 : -20.0), qx, qy, W);
+            ex = std::max(ex, std::fabs(qx - p0x)); ey = std::max(ey, std::fabs(qy - p0y));
+        }
+    }
+    if (!(ex < 4096 && ey < 4096)) return false;
+    const int hx = (int)std::ceil(ex) + 2, hy = (int)std::ceil(ey) + 2, pw = 2 * hx + 2, ph = 2 * hy + 2, cn = wa.src_cn;
+    const int pitch_i = (15 + (pw - 2) * cn + 8 + 15) & ~15, pitch_w = (15 + pw * 4 + 15) & ~15;
+    if ((pitch_i >> 4) + (pitch_w >> 4) > 64) return false;                    // one wave stages one patch row per round
+    if ((long)ph * (pitch_i + pitch_w) > kPatchBytes) return false;
+    for (int i = 0; i < 9; i++) w.Mf[i] = (float)M[i];
+    w.phx = hx; w.phy = hy; w.pitch_i = pitch_i; w.pitch_w = pitch_w;
+    return true;
 }
 
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
@@ -1231,7 +1453,13 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         J.g.nbx = (q.cx1 - q.cx0 + LBW - 1) / LBW; J.g.nby = (q.cy1 - q.cy0 + BH - 1) / BH;
         if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
-        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.mask = q.mask; J.from_warp = q.from_warp;
+        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
+        J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
+        for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        if (batch.njobs == 0 && q.table_args && q.table_n > 0 && q.table_n <= kArgTable) {
+            batch.tab0_n = q.table_n;
+            for (int i = 0; i < q.table_n; i++) batch.tab0[i] = q.table_args[i];
+        }
         // job 0 has its own block numbering, jobs 1.. share one (see k_levels)
         const int padded = (J.g.nbx * J.g.nby + 7) & ~7;
         if (batch.njobs == 0) { J.first = 0; first_blocks = padded; }
@@ -1243,7 +1471,8 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // measured on MI355X (tools/ab.sh, cfg-A fp32): upper levels dealt between the level-0 groups 156 us per launch, upper
     // levels last 151 us -- a latency-bound workgroup in a slot costs the level-0 phase more than the tail costs
     static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
-    batch.sequential = !interleave;
+    static const bool upper_first = getenv("PF_UPPER_FIRST") != nullptr;
+    batch.sequential = upper_first ? 2 : !interleave;
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {
@@ -1264,6 +1493,12 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         }
     }
 #define PF_GO(F, H, T, S, I) hipLaunchKernelGGL((k_levels<F, H, T, S, I>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
+    // level 0 with LDS-staged source patches when the frame's map allows it (patch_plan)
+    if (wa && !st && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
+        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        return;
+    }
     if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)
         if (lay.f32) { if (ilp == 3) PF_GO(true, 64, 1024, false, 3); else PF_GO(true, 64, 1024, false, 2); }
         else if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);

@@ -76,15 +76,23 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
 
 // Pipelined form of the same kernel: ONE launch carries several independent level jobs (level 0 of the
 // newest frame, level 1 of the frame before it, ...), each with its own tile table and GW buffers.
+constexpr int kArgTable = 256;      // tile-table entries that can travel inside the kernel arguments of a launch
+constexpr int kMaxRects = 8;        // need rectangles per level job (tile-sharded canvases)
+struct BlockRect { short x0, y0, x1, y1; };      // [x0,x1) x [y0,y1) in blocks of the job's block grid
 struct LevelLaunch {
     int level, rows, cols;          // pyramid level and its canvas extent
     int cx0, cy0, cx1, cy1;         // compute region
     int tiles_x;
     bool top_select, write_next, from_warp;
     const void* gw_in; void* gw_out;
-    const uint64_t* table;
-    const uint8_t* mask;            // nullptr, or one byte per 64x32 block of the compute region (row-major): 0 = nothing of this
-                                    // rank's tiles depends on the block (tile-sharded canvases), skip it
+    const uint64_t* table;          // the frame's tile table in device memory
+    // level-0 job only: the table's entries on the host (n <= kArgTable).  They travel in the launch's kernel arguments --
+    // visible to the launch by the runtime's own contract, no copy in the stream, no host memory read in place --
+    // and the launch itself stores them to `table` for the later launches that carry the frame's upper levels.
+    const uint64_t* table_args; int table_n;
+    // tile-sharded canvases: the union of these rectangles holds every block something owned by this rank depends on;
+    // the other blocks of the grid exit at once.  nrect == 0: every block runs.
+    int nrect; BlockRect rect[kMaxRects];
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);
