@@ -288,6 +288,8 @@ def roofline_record(dom, p, dtype_key, event_every):
     launches = max(p["launches"], 1)
     us = p["ms"] / launches * 1e3
     pmc = pmc_record(dtype_key, dom)
+    # "bound" names the roofline `achieved`/`peak` are priced against (HBM bytes: north_star asks for % of the HBM roofline);
+    # "limiter" below says what the counters show the launch is actually held by
     rec = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4),
            "traffic": pmc.get("traffic") if pmc else None,
@@ -534,11 +536,21 @@ def main():
                 out["map2dcpu_single_band"] = guarded(map2dcpu_rates, pf, wl, my_sortie, prep, frames, hostf)
     if rank == 0:
         real_out.write(json.dumps(out) + "\n"); real_out.flush()
+    # Teardown that cannot hang: the main measurement is printed; a rank whose probe was abandoned (a collective that never
+    # returned) leaves at once with a non-zero code, and the ranks that did finish wait for their peers under a deadline too
+    # -- otherwise they would sit in the barrier until the backend's own timeout.  Exit codes: 3 = this rank's probe hung,
+    # 4 = a peer never reached the final barrier.  No re-exec, no restart of a GPU process.
     if abandoned:
-        os._exit(0)                       # a peer may sit in a collective for ever: the line is out, leave without the teardown
+        sys.stderr.write("bench.py: rank %d abandons the strong probe (no result within the deadline)\n" % rank); sys.stderr.flush()
+        os._exit(3)
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        def fin():
+            dist.barrier()
+            dist.destroy_process_group()
+        rec, late = run_with_deadline(fin, 90)
+        if late or (isinstance(rec, dict) and "error" in rec):
+            sys.stderr.write("bench.py: rank %d: final barrier not reached by every rank (%s)\n" % (rank, rec)); sys.stderr.flush()
+            os._exit(4)
 
 
 if __name__ == "__main__":

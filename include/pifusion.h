@@ -193,8 +193,28 @@ typedef struct pf_dist_stats {
     unsigned long long bytes_sent, bytes_received;   /* payload, this rank */
     unsigned long long strips_sent, strips_received, tiles, peers;
     double plan_ms, pack_ms, exchange_ms, compute_ms;
+    unsigned long long verified;                      /* data exchanges checked end to end in this call (PF_DIST_VERIFY=1: every
+                                                       * rank hashes what it sent to and received from each peer; the hashes must agree) */
 } pf_dist_stats;
 int      pf_dist_last_stats(pf_dist* d, pf_dist_stats* out);
+/* The plan of one pf_dist_blend_changed call as rank `me` derives it from the all-gathered tile lists -- a pure function
+ * (no device, no transport), exported so that launchers and the CPU tests can inspect or replay the exchange the library
+ * will make.  lists: for every rank, counts[r] records of 3 ints (ix, iy, Ischanged), ranks back to back; caps[r]: the most
+ * tiles rank r blends in the call; halo_bytes9[j]: bytes of the strip set of neighbour j = 3*(dy+1)+(dx+1) (pf_halo_bytes).
+ * send[i]: tile (ix,iy) of THIS rank hands the edge facing (-dx,-dy) to rank `peer`, at byte `offset` of the bytes for that
+ * peer; recv[i]: this rank's tile number `tile` (index into mine_xy) gets neighbour j = 3*(dy+1)+(dx+1) from rank `peer` at
+ * byte `offset` of the bytes from that peer.  Returns 1, or 0 when a capacity is too small (the n_* still say what is needed). */
+typedef struct pf_strip_plan { int peer, ix, iy, dx, dy, tile; unsigned long long offset; } pf_strip_plan;
+int      pf_dist_plan_blend(int nranks, int me, const int* counts, const int* lists3, const long long* caps, int high_quality,
+                            const size_t halo_bytes9[9], pf_strip_plan* send, int send_cap, int* n_send,
+                            pf_strip_plan* recv, int recv_cap, int* n_recv, int* mine_xy, int mine_cap, int* n_mine);
+/* what the group looks like from this rank: its rank, the number of ranks the transport was brought up with, and the
+ * transport's name ("rccl" / "host").  A launcher's first multi-GPU run checks these before it trusts a collective.  */
+int      pf_dist_info(pf_dist* d, int* rank, int* nranks, const char** transport);
+/* end-to-end check of every data exchange of the following pf_dist_* calls (default: on iff PF_DIST_VERIFY is set): each
+ * rank hashes (FNV-1a) what it sent to and what it received from each peer, the hashes travel as a control message and
+ * must agree; a mismatch fails the call and pf_last_error names the pair.  Costs a device-to-host copy of the payload. */
+int      pf_dist_set_verify(pf_dist* d, int on);
 
 /* --- measurement -------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the map's own stream.  mode 0 = off,

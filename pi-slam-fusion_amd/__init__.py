@@ -36,7 +36,8 @@ class Image(C.Structure):
 class DistStats(C.Structure):
     _fields_ = [("bytes_sent", C.c_ulonglong), ("bytes_received", C.c_ulonglong), ("strips_sent", C.c_ulonglong),
                 ("strips_received", C.c_ulonglong), ("tiles", C.c_ulonglong), ("peers", C.c_ulonglong),
-                ("plan_ms", C.c_double), ("pack_ms", C.c_double), ("exchange_ms", C.c_double), ("compute_ms", C.c_double)]
+                ("plan_ms", C.c_double), ("pack_ms", C.c_double), ("exchange_ms", C.c_double), ("compute_ms", C.c_double),
+                ("verified", C.c_ulonglong)]
 
 
 # pf_exchange_fn: all-to-all-v over host buffers (include/pifusion.h)
@@ -110,6 +111,10 @@ def lib():
     L.pf_dist_save.argtypes = [vp, C.c_char_p]
     L.pf_dist_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
     L.pf_dist_last_stats.argtypes = [vp, C.POINTER(DistStats)]
+    L.pf_dist_info.argtypes = [vp, ip, ip, C.POINTER(C.c_char_p)]
+    L.pf_dist_set_verify.argtypes = [vp, C.c_int]
+    L.pf_dist_plan_blend.argtypes = [C.c_int, C.c_int, ip, ip, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_size_t), vp, C.c_int, ip,
+                                     vp, C.c_int, ip, ip, C.c_int, ip]
     L.pf_profile_enable.argtypes = [vp, C.c_int]
     L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
     L.pf_profile_reset.argtypes = [vp]

@@ -138,6 +138,42 @@ int pf_dist_save(pf_dist* d, const char* filename) { return d && filename && d->
 int pf_dist_save_to_memory(pf_dist* d, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return d && rows && cols && tx0 && ty0 && d->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
 int pf_dist_last_stats(pf_dist* d, pf_dist_stats* out) { if (!d || !out) return 0; *out = d->impl.stats(); return 1; }
+int pf_dist_plan_blend(int nranks, int me, const int* counts, const int* lists3, const long long* caps, int high_quality,
+                       const size_t halo_bytes9[9], pf_strip_plan* send, int send_cap, int* n_send,
+                       pf_strip_plan* recv, int recv_cap, int* n_recv, int* mine_xy, int mine_cap, int* n_mine)
+{
+    if (nranks < 1 || me < 0 || me >= nranks || !counts || !lists3 || !caps || !halo_bytes9 || !n_send || !n_recv || !n_mine) return 0;
+    std::vector<std::vector<pf::FusionMap::TileRec>> all(nranks);
+    std::vector<long long> cp(caps, caps + nranks);
+    const int* q = lists3;
+    for (int r = 0; r < nranks; r++)
+        for (int k = 0; k < counts[r]; k++, q += 3) all[r].push_back({ q[0], q[1], q[2] });
+    pf::BlendPlan plan;
+    pf::plan_blend(all, cp, me, high_quality != 0, halo_bytes9, plan);
+    int ns = 0, nr = (int)plan.wants.size(), nm = (int)plan.mine.size();
+    for (auto& v : plan.send_req) ns += (int)v.size();
+    *n_send = ns; *n_recv = nr; *n_mine = nm;
+    if (ns > send_cap || nr > recv_cap || nm > mine_cap || (ns && !send) || (nr && !recv) || (nm && !mine_xy)) return 0;
+    int i = 0;
+    for (int p = 0; p < nranks; p++)
+        for (auto& rq : plan.send_req[p]) send[i++] = pf_strip_plan{ p, rq.ix, rq.iy, rq.dx, rq.dy, -1, (unsigned long long)rq.out_off };
+    for (int k = 0; k < nr; k++) {
+        const auto& w = plan.wants[k];
+        recv[k] = pf_strip_plan{ w.peer, plan.mine[w.tile].first, plan.mine[w.tile].second, w.j % 3 - 1, w.j / 3 - 1, w.tile, (unsigned long long)w.off };
+    }
+    for (int k = 0; k < nm; k++) { mine_xy[2 * k] = plan.mine[k].first; mine_xy[2 * k + 1] = plan.mine[k].second; }
+    return 1;
+}
+int pf_dist_set_verify(pf_dist* d, int on) { if (!d) return 0; d->impl.set_verify(on != 0); return 1; }
+int pf_dist_info(pf_dist* d, int* rank, int* nranks, const char** transport)
+{
+    if (!d) return 0;
+    const pf::Transport* t = d->impl.transport();
+    if (rank) *rank = t->rank;
+    if (nranks) *nranks = t->nranks;
+    if (transport) *transport = t->name();
+    return 1;
+}
 
 int pf_profile_enable(pf_map* m, int mode) { if (!m) return 0; m->impl.profile_enable(mode); return 1; }
 int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes)

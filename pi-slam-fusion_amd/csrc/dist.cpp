@@ -16,8 +16,11 @@
 #include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <string>
 
 namespace pf {
 
@@ -202,7 +205,7 @@ Transport* make_rccl_transport(const void* id128, int rank, int nranks, int devi
 Transport* make_host_transport(int rank, int nranks, pf_exchange_fn fn, void* user) { return fn ? new HostTransport(rank, nranks, fn, user) : nullptr; }
 
 // ------------------------------------------------------------------ DistMap
-DistMap::DistMap(FusionMap* m, Transport* t) : m_(m), t_(t) {}
+DistMap::DistMap(FusionMap* m, Transport* t) : m_(m), t_(t) { verify_ = std::getenv("PF_DIST_VERIFY") != nullptr; }
 DistMap::~DistMap() { delete t_; send_.release(); recv_.release(); }
 
 // every rank's tile list (coordinates + Ischanged) on every rank: sizes first, then the records
@@ -232,6 +235,107 @@ bool DistMap::gather_lists(std::vector<std::vector<FusionMap::TileRec>>& all, st
     return t_->exchange_host(s, sb, r, rb, st);
 }
 
+// Every rank reports whether its side of the step so far went well; true iff all did.  A rank that failed locally (an
+// allocation, a tile it does not hold) must not leave its peers waiting in the data exchange: everybody returns together.
+bool DistMap::agree(bool ok_here)
+{
+    const int n = t_->nranks, me = t_->rank;
+    if (n == 1) return ok_here;
+    int mine = ok_here ? 1 : 0;
+    std::vector<int> theirs(n, 1);
+    std::vector<const void*> s(n, &mine); std::vector<void*> r(n, nullptr);
+    std::vector<size_t> sb(n, sizeof(int)), rb(n, sizeof(int));
+    for (int p = 0; p < n; p++) r[p] = &theirs[p];
+    sb[me] = rb[me] = 0;
+    if (!t_->exchange_host(s, sb, r, rb, m_->stream())) return false;
+    bool all = ok_here;
+    for (int p = 0; p < n; p++) if (p != me && !theirs[p]) { all = false; set_error("dist: rank " + std::to_string(p) + " reported a failure before the exchange"); }
+    return all;
+}
+
+static uint64_t fnv1a(const unsigned char* p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// the data exchange, optionally verified (PF_DIST_VERIFY=1): every rank hashes what it sent to each peer and what it
+// received from each peer; the hashes travel as a control message and must agree -- a first multi-GPU run that moves
+// wrong bytes says which pair and how many bytes instead of producing a wrong mosaic
+bool DistMap::exchange_checked(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                               const std::vector<size_t>& rb, const char* what)
+{
+    if (!t_->exchange_dev(send, sb, recv, rb, m_->stream())) return false;
+    if (!verify_) return true;
+    const int n = t_->nranks, me = t_->rank;
+    struct Sum { uint64_t hash; uint64_t bytes; };
+    std::vector<Sum> sent(n), got(n), claimed(n);
+    std::vector<unsigned char> tmp;
+    for (int p = 0; p < n; p++) {
+        sent[p] = { 0, sb[p] }; got[p] = { 0, rb[p] };
+        if (p == me) continue;
+        if (sb[p]) { tmp.resize(sb[p]); HIP_OK(hipMemcpy(tmp.data(), send[p], sb[p], hipMemcpyDeviceToHost)); sent[p].hash = fnv1a(tmp.data(), sb[p]); }
+        if (rb[p]) { tmp.resize(rb[p]); HIP_OK(hipMemcpy(tmp.data(), recv[p], rb[p], hipMemcpyDeviceToHost)); got[p].hash = fnv1a(tmp.data(), rb[p]); }
+    }
+    std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
+    std::vector<size_t> hs(n, sizeof(Sum)), hr(n, sizeof(Sum));
+    for (int p = 0; p < n; p++) { s[p] = &sent[p]; r[p] = &claimed[p]; }
+    hs[me] = hr[me] = 0;
+    if (!t_->exchange_host(s, hs, r, hr, m_->stream())) return false;
+    bool ok = true;
+    for (int p = 0; p < n; p++) {
+        if (p == me) continue;
+        if (claimed[p].bytes != got[p].bytes || (got[p].bytes && claimed[p].hash != got[p].hash)) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "dist verify (%s): rank %d sent %llu bytes (fnv %016llx), rank %d received %llu bytes (fnv %016llx)",
+                          what, p, (unsigned long long)claimed[p].bytes, (unsigned long long)claimed[p].hash, me,
+                          (unsigned long long)got[p].bytes, (unsigned long long)got[p].hash);
+            set_error(msg);
+            ok = false;
+        }
+    }
+    stats_.verified += ok ? 1 : 0;
+    return ok;
+}
+
+// The plan of one draw() across ranks, from the all-gathered tile lists alone (no device, no transport: also exported as
+// pf_dist_plan_blend so that the CPU tests run THIS code between processes).  For rank r's changed tile whose 3x3
+// neighbourhood exists somewhere (Ele::blend's condition, .cpp:93-117), every neighbour held by another rank p contributes
+// one strip set p -> r.  Order: requester's tiles by (iy,ix), neighbours by j = 3*(dy+1)+(dx+1); every rank derives the
+// same order, so no header travels with the payload.
+void plan_blend(const std::vector<std::vector<FusionMap::TileRec>>& all, const std::vector<long long>& caps, int me, bool hq,
+                const size_t halo_bytes9[9], BlendPlan& out)
+{
+    const int n = (int)all.size();
+    std::map<std::pair<int, int>, int> owner;                 // (ix,iy) -> rank holding it
+    for (int p = 0; p < n; p++) for (auto& t : all[p]) owner[{ t.ix, t.iy }] = p;
+    out.send_bytes.assign(n, 0); out.recv_bytes.assign(n, 0);
+    out.send_req.assign(n, {});
+    out.wants.clear(); out.mine.clear();
+    for (int r = 0; r < n; r++) {
+        long long taken = 0;
+        for (auto& t : all[r]) {
+            if (!t.changed) continue;
+            if (taken >= caps[r]) break;                      // rank r blends at most its own cap tiles in this call
+            if (r == me) out.mine.push_back({ t.ix, t.iy });
+            taken++;
+            if (!hq) continue;
+            bool full = true;
+            for (int j = 0; j < 9 && full; j++) full = owner.count({ t.ix + j % 3 - 1, t.iy + j / 3 - 1 }) != 0;
+            if (!full) continue;                              // blends alone (.cpp:134-145): no strips
+            for (int j = 0; j < 9; j++) {
+                if (j == 4) continue;
+                const int dx = j % 3 - 1, dy = j / 3 - 1, p = owner[{ t.ix + dx, t.iy + dy }];
+                if (p == r) continue;
+                const size_t nb = halo_bytes9[j];
+                if (p == me) { out.send_req[r].push_back({ t.ix + dx, t.iy + dy, dx, dy, out.send_bytes[r] }); out.send_bytes[r] += nb; }
+                if (r == me) { out.wants.push_back({ (int)out.mine.size() - 1, j, p, out.recv_bytes[p] }); out.recv_bytes[p] += nb; }
+            }
+        }
+    }
+}
+
 // draw() across ranks: blend this rank's changed tiles, with the strips of neighbours that live elsewhere
 int DistMap::blend_changed(int* xy, uint8_t* bgr, int cap)
 {
@@ -242,54 +346,33 @@ int DistMap::blend_changed(int* xy, uint8_t* bgr, int cap)
     std::vector<std::vector<FusionMap::TileRec>> all;
     std::vector<long long> caps;
     if (!gather_lists(all, caps, cap)) return -1;
-    std::map<std::pair<int, int>, int> owner;                 // (ix,iy) -> rank holding it
-    for (int p = 0; p < n; p++) for (auto& t : all[p]) owner[{ t.ix, t.iy }] = p;
-
-    // plan: for rank r's changed tile whose 3x3 neighbourhood exists somewhere, every neighbour on another rank p
-    // contributes one strip set p -> r.  Order: requester's tiles by (iy,ix), neighbours by j = 3*(dy+1)+(dx+1).
-    std::vector<size_t> send_bytes(n, 0), recv_bytes(n, 0);
-    std::vector<std::vector<FusionMap::StripReq>> send_req(n);
-    struct Want { int tile, j, peer; size_t off; };
-    std::vector<Want> wants;
-    std::vector<std::pair<int, int>> mine;                    // this rank's changed tiles, in order, at most cap
-    const bool hq = m_->high_quality();
-    for (int r = 0; r < n; r++) {
-        int taken = 0;
-        for (auto& t : all[r]) {
-            if (!t.changed) continue;
-            if (taken >= caps[r]) break;                      // rank r blends at most its own cap tiles in this call
-            if (r == me) mine.push_back({ t.ix, t.iy });
-            taken++;
-            if (!hq) continue;
-            bool full = true;
-            for (int j = 0; j < 9 && full; j++) full = owner.count({ t.ix + j % 3 - 1, t.iy + j / 3 - 1 }) != 0;
-            if (!full) continue;                              // blends alone (.cpp:134-145): no strips
-            for (int j = 0; j < 9; j++) {
-                if (j == 4) continue;
-                const int dx = j % 3 - 1, dy = j / 3 - 1, p = owner[{ t.ix + dx, t.iy + dy }];
-                if (p == r) continue;
-                const size_t nb = m_->halo_bytes_for(dx, dy);
-                if (p == me) { send_req[r].push_back({ t.ix + dx, t.iy + dy, dx, dy, send_bytes[r] }); send_bytes[r] += nb; }
-                if (r == me) { wants.push_back({ (int)mine.size() - 1, j, p, recv_bytes[p] }); recv_bytes[p] += nb; }
-            }
-        }
-    }
+    // plan (pure function of the gathered lists, shared by every rank): who packs which strip for whom
+    size_t hb9[9];
+    for (int j = 0; j < 9; j++) hb9[j] = j == 4 ? 0 : m_->halo_bytes_for(j % 3 - 1, j / 3 - 1);
+    BlendPlan plan;
+    plan_blend(all, caps, me, m_->high_quality(), hb9, plan);
+    std::vector<size_t>& send_bytes = plan.send_bytes;
+    std::vector<size_t>& recv_bytes = plan.recv_bytes;
+    std::vector<std::vector<FusionMap::StripReq>>& send_req = plan.send_req;
+    std::vector<BlendPlan::Want>& wants = plan.wants;
+    std::vector<std::pair<int, int>>& mine = plan.mine;
     // one send buffer and one receive buffer, peers back to back
     std::vector<size_t> soff(n, 0), roff(n, 0);
     size_t ts = 0, tr = 0;
     for (int p = 0; p < n; p++) { soff[p] = ts; ts += (send_bytes[p] + 255) / 256 * 256; roff[p] = tr; tr += (recv_bytes[p] + 255) / 256 * 256; }
-    if (!send_.reserve(ts + 256) || !recv_.reserve(tr + 256)) return -1;
+    bool ok_here = send_.reserve(ts + 256) && recv_.reserve(tr + 256);
     std::vector<FusionMap::StripReq> reqs;
     for (int p = 0; p < n; p++) for (auto q : send_req[p]) { q.out_off += soff[p]; reqs.push_back(q); }
     const auto t_pack = std::chrono::steady_clock::now();
-    if (!m_->pack_strips(reqs, send_.p)) return -1;           // ONE launch, ONE sync
+    ok_here = ok_here && m_->pack_strips(reqs, send_.p);      // ONE launch, ONE sync
+    if (!agree(ok_here)) return -1;                           // every rank leaves here, or none does
     const auto t_xchg = std::chrono::steady_clock::now();
     if (n > 1) {
         std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
         for (int p = 0; p < n; p++) { s[p] = (char*)send_.p + soff[p]; r[p] = (char*)recv_.p + roff[p]; }
         std::vector<size_t> sb = send_bytes, rb = recv_bytes;
         sb[me] = rb[me] = 0;
-        if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return -1;      // returns with the stream drained: the bytes have landed
+        if (!exchange_checked(s, sb, r, rb, "blend strips")) return -1;    // returns with the stream drained: the bytes have landed
     }
     const auto t_blend = std::chrono::steady_clock::now();
     std::vector<const void*> halo9(mine.size() * 9, nullptr);
@@ -332,10 +415,10 @@ bool DistMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* 
     if (me != 0) {
         std::vector<std::pair<int, int>> mine;
         for (auto& t : all[me]) mine.push_back({ t.ix, t.iy });
-        if (!send_.reserve(nb * mine.size() + 256)) return false;
-        if (!m_->export_tiles(mine, send_.p)) return false;
+        const bool ok_here = send_.reserve(nb * mine.size() + 256) && m_->export_tiles(mine, send_.p);
+        if (!agree(ok_here)) return false;
         s[0] = send_.p; sb[0] = nb * mine.size();
-        if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return false;
+        if (!exchange_checked(s, sb, r, rb, "save tiles")) return false;
         stats_.bytes_sent = sb[0]; stats_.tiles = mine.size();
         *rows = *cols = 0; *tx0 = *ty0 = 0;
         stats_.exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -344,9 +427,9 @@ bool DistMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* 
     size_t total = 0;
     std::vector<size_t> off(n, 0);
     for (int p = 1; p < n; p++) { off[p] = total; total += nb * all[p].size(); }
-    if (!recv_.reserve(total + 256)) return false;
+    if (!agree(recv_.reserve(total + 256))) return false;
     for (int p = 1; p < n; p++) { r[p] = (char*)recv_.p + off[p]; rb[p] = nb * all[p].size(); }
-    if (!t_->exchange_dev(s, sb, r, rb, m_->stream())) return false;
+    if (!exchange_checked(s, sb, r, rb, "save tiles")) return false;
     const auto t_x = std::chrono::steady_clock::now();
     std::vector<FusionMap::ForeignTile> foreign;
     for (int p = 1; p < n; p++)

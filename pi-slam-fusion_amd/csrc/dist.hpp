@@ -19,6 +19,17 @@ bool rccl_unique_id(void* out128);
 Transport* make_rccl_transport(const void* id128, int rank, int nranks, int device);
 Transport* make_host_transport(int rank, int nranks, pf_exchange_fn fn, void* user);
 
+// plan of one draw() across ranks (dist.cpp, plan_blend)
+struct BlendPlan {
+    std::vector<size_t> send_bytes, recv_bytes;                       // per peer
+    std::vector<std::vector<FusionMap::StripReq>> send_req;           // per requesting peer: this rank's tile to pack, offset inside the peer's region
+    struct Want { int tile, j, peer; size_t off; };                   // this rank's tile `tile` (index in mine) gets neighbour j from peer
+    std::vector<Want> wants;
+    std::vector<std::pair<int, int>> mine;                            // this rank's changed tiles, in blend order, at most its cap
+};
+void plan_blend(const std::vector<std::vector<FusionMap::TileRec>>& all, const std::vector<long long>& caps, int me, bool hq,
+                const size_t halo_bytes9[9], BlendPlan& out);
+
 class DistMap {
 public:
     DistMap(FusionMap* m, Transport* t);      // takes the transport
@@ -28,12 +39,17 @@ public:
     bool save(const char* filename);
     const pf_dist_stats& stats() const { return stats_; }
     const Transport* transport() const { return t_; }
+    void set_verify(bool on) { verify_ = on; }
 private:
     bool gather_lists(std::vector<std::vector<FusionMap::TileRec>>& all, std::vector<long long>& caps, long long my_cap);
+    bool agree(bool ok_here);
+    bool exchange_checked(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
+                          const std::vector<size_t>& rb, const char* what);
     FusionMap* m_;
     Transport* t_;
     DevBuf send_, recv_;
     pf_dist_stats stats_{};
+    bool verify_ = false;                       // PF_DIST_VERIFY=1 or pf_dist_set_verify: hash every data exchange on both ends
 };
 
 }  // namespace pf

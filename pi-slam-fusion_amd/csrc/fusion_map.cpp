@@ -939,6 +939,15 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
     return true;
 }
 
+// Everything that writes tile slots is ordered before what the caller enqueues on stream_ next (blend, strip pack, tile
+// export).  Pipelined path: the pending upper-level launches go onto stream_ itself.  fused = 0/2/3 run pyramid levels on
+// streams of their own: wait for those.
+bool FusionMap::settle()
+{
+    if (opt_.fused == 1 || single_band_) return flush_pipeline();
+    return sync_all() == hipSuccess;
+}
+
 // run the upper levels still pending for the frames fed so far (at most L-1 small launches)
 bool FusionMap::flush_pipeline()
 {
@@ -1056,7 +1065,7 @@ bool FusionMap::pack_strips(const std::vector<StripReq>& reqs, void* dev_out)
     std::lock_guard<std::mutex> l(mu_);
     if (!init_ok_ || !set_device()) return false;
     if (reqs.empty()) return true;
-    if (!flush_pipeline()) return false;
+    if (!settle()) return false;
     std::vector<StripDesc> d(reqs.size());
     for (size_t i = 0; i < reqs.size(); i++) {
         Tile* t = store_.find(reqs[i].ix, reqs[i].iy);
@@ -1076,7 +1085,7 @@ bool FusionMap::export_tiles(const std::vector<std::pair<int, int>>& tiles, void
 {
     std::lock_guard<std::mutex> l(mu_);
     if (!init_ok_ || !set_device()) return false;
-    if (!flush_pipeline()) return false;
+    if (!settle()) return false;
     for (size_t i = 0; i < tiles.size(); i++) {
         Tile* t = store_.find(tiles[i].first, tiles[i].second);
         if (!t || t->fresh) { set_error("export_tiles: tile not held by this rank"); return false; }
@@ -1106,7 +1115,7 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     const size_t tile_px = (size_t)kElePixels * kElePixels;
     constexpr size_t kChunk = 128;
-    if (!flush_pipeline()) return false;          // the upper levels of the last frames are still pending: run them first (stream order)
+    if (!settle()) return false;                  // the upper levels of the last frames are still pending: run them first (stream order)
     for (size_t c0 = 0; c0 < tiles.size(); c0 += kChunk) {
         const size_t cn = std::min(kChunk, tiles.size() - c0);
         if (raw_host && !blend_out_raw_.reserve(tile_px * px * cn)) return false;

@@ -198,6 +198,7 @@ private:
     bool flushing_ = false;
     bool launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const uint8_t* src);
     bool flush_pipeline();
+    bool settle();
 
     // blend / save scratch
     DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_, strip_desc_;

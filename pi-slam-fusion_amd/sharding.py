@@ -9,10 +9,10 @@ recomputes the pyramid halo from the source frame.  The only exchange steps are
     moved with ONE all_to_all (point-to-point traffic over xGMI, all links at once);
   * save (.cpp:779-847): whole tiles are gathered to rank 0, which runs the mosaic collapse.
 
-On a GPU the exchange lives in the library (csrc/dist.cpp, C ABI pf_dist_*: one pack launch, one grouped
-ncclSend/ncclRecv exchange, one batched blend per call); `DistMap` below is its thin caller.  The functions
-after it are the same plan in Python over torch.distributed and an engine interface: the CPU model of the
-exchange that tests/test_sharding_gloo.py runs with an oracle-backed engine (no GPU there).
+The exchange lives in the library (csrc/dist.cpp, C ABI pf_dist_*: one pack launch, one grouped ncclSend/ncclRecv
+exchange, one batched blend per call); `DistMap` below is its thin caller, `torch_exchange` the host-buffer hook for
+launchers without RCCL, `plan_blend` the library's own exchange plan (pf_dist_plan_blend, a pure function) as the CPU
+tests replay it between gloo processes (tests/test_sharding_gloo.py).
 """
 import ctypes as C
 
@@ -112,6 +112,16 @@ class DistMap:
     def save(self, filename):
         return bool(_pkg().lib().pf_dist_save(self._h, filename.encode()))
 
+    def set_verify(self, on=True):
+        """hash every data exchange of the following calls on both ends (pf_dist_set_verify)"""
+        _pkg().lib().pf_dist_set_verify(self._h, 1 if on else 0)
+
+    def info(self):
+        """(rank, nranks, transport name) as the library's transport sees the group"""
+        r, n, name = C.c_int(), C.c_int(), C.c_char_p()
+        _pkg().lib().pf_dist_info(self._h, C.byref(r), C.byref(n), C.byref(name))
+        return {"rank": r.value, "nranks": n.value, "transport": (name.value or b"").decode()}
+
     def stats(self):
         st = _pkg().DistStats()
         _pkg().lib().pf_dist_last_stats(self._h, C.byref(st))
@@ -127,13 +137,23 @@ def strong_report(m, rank, world, backend, group=None):
     m.sync()
     if world > 1:
         dist.barrier(group)
+    # a first, small draw() with every exchanged byte hashed on both ends (says which pair moved wrong bytes, if any), then
+    # the timed one over the remaining tiles without the check
+    d.set_verify(True)
+    first, _ = d.blend_changed(cap=min(32, max(1, len(m.tiles()))))
+    verified = d.stats()["verified"]
+    d.set_verify(False)
+    if world > 1:
+        dist.barrier(group)
     t0 = time.perf_counter(); coords, _ = d.blend_changed(); t_blend = time.perf_counter() - t0
     st_b = d.stats()
+    st_b["verified"] = verified
+    coords = first + coords
     if world > 1:
         dist.barrier(group)
     t0 = time.perf_counter(); saved = d.save_to_memory(); t_save = time.perf_counter() - t0
     st_s = d.stats()
-    mine = {"rank": rank, "tiles": len(m.tiles()), "blended": len(coords), "render": rs, "blend_s": t_blend, "blend": st_b,
+    mine = {"rank": rank, "tiles": len(m.tiles()), "blended": len(coords), "render": rs, "blend_s": t_blend, "blend": st_b, "info": d.info(),
             "save_s": t_save, "save": st_s, "mosaic": None if saved is None else list(saved[0].shape[:2])}
     got = [None] * world
     if world > 1:
@@ -148,6 +168,10 @@ def strong_report(m, rank, world, backend, group=None):
     gathered = got[0]["save"]["bytes_received"]
     return {
         "transport": "rccl" if backend == "nccl" else "host-buffer hook over torch.distributed (%s)" % backend,
+        # what the library's own communicator reports on every rank (a first multi-GPU run checks this before anything else)
+        "communicator": {"nranks_seen": [g["info"]["nranks"] for g in got], "ranks_seen": [g["info"]["rank"] for g in got],
+                         "transport": got[0]["info"]["transport"],
+                         "verified_exchanges": [g["blend"]["verified"] + g["save"]["verified"] for g in got]},
         "tiles_per_rank": [g["tiles"] for g in got],
         "halo_recompute_factor_per_rank": [round(g["render"]["level0_px"] / max(g["render"]["owned_px"], 1.0), 3) for g in got],
         "frames_with_pixels_per_rank": [g["render"]["frames_with_pixels"] for g in got],
@@ -163,145 +187,28 @@ def strong_report(m, rank, world, backend, group=None):
     }
 
 
-class GpuEngine:
-    """Adapter of a pi_slam_fusion_amd.Map2D to the exchange interface (device tensors)."""
-
-    def __init__(self, m, device):
-        self.m, self.device = m, device
-
-    def tiles(self):
-        return self.m.tiles()
-
-    def halo_bytes(self, dx, dy):
-        return self.m.halo_bytes(dx, dy)
-
-    def tile_bytes(self):
-        return self.m.tile_bytes()
-
-    def empty(self, nbytes):
-        return torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
-
-    def pack_halo(self, ix, iy, dx, dy, out):
-        assert self.m.halo_pack(ix, iy, dx, dy, out.data_ptr())
-
-    def blend_with_halo(self, ix, iy, halos, raw=False):
-        return self.m.blend_tile_halo(ix, iy, [h.data_ptr() if h is not None else 0 for h in halos], raw=raw)
-
-    def export_tile(self, ix, iy, out):
-        assert self.m.tile_export(ix, iy, out.data_ptr())
-
-    def import_tile(self, ix, iy, buf):
-        assert self.m.tile_import(ix, iy, buf.data_ptr())
+class StripPlan(C.Structure):
+    _fields_ = [("peer", C.c_int), ("ix", C.c_int), ("iy", C.c_int), ("dx", C.c_int), ("dy", C.c_int), ("tile", C.c_int),
+                ("offset", C.c_ulonglong)]
 
 
-def all_tile_lists(engine, group=None):
-    """Every rank's tile list on every rank (tiny all_gather of coordinates)."""
-    world = dist.get_world_size(group)
-    mine = engine.tiles()
-    out = [None] * world
-    dist.all_gather_object(out, mine, group=group)
-    return out
-
-
-def plan_halo_exchange(tile_lists, rank):
-    """Which strips this rank must send / will receive so that every rank can blend its tiles.
-
-    A strip is identified by (requesting tile, dx, dy): the tile at (ix+dx, iy+dy) hands over
-    the edge that blend() copies from it (.cpp:101-116).  Returns (send, recv): per peer rank an
-    ordered list of (ix, iy, dx, dy); both sides derive the same order, so no header travels."""
-    world = len(tile_lists)
-    owner = {}
-    for r, tl in enumerate(tile_lists):
-        for t in tl:
-            owner[tuple(t)] = r
-    send = [[] for _ in range(world)]
-    recv = [[] for _ in range(world)]
-    for r, tl in enumerate(tile_lists):
-        for (ix, iy) in sorted(tuple(t) for t in tl):
-            for (dx, dy) in NEIGHBOURS:
-                if dx == 0 and dy == 0:
-                    continue
-                o = owner.get((ix + dx, iy + dy))
-                if o is None or o == r:
-                    continue
-                if r == rank:
-                    recv[o].append((ix, iy, dx, dy))
-                if o == rank:
-                    send[r].append((ix, iy, dx, dy))
-    return send, recv
-
-
-def exchange_halos(engine, group=None):
-    """All ranks: pack the strips the others need, one all_to_all, return
-    {(ix,iy): [9 tensors or None]} for this rank's tiles."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lists = all_tile_lists(engine, group)
-    send, recv = plan_halo_exchange(lists, rank)
-    size = {(dx, dy): engine.halo_bytes(dx, dy) for (dx, dy) in NEIGHBOURS if (dx, dy) != (0, 0)}
-    send_sizes = [sum(size[(dx, dy)] for (_, _, dx, dy) in send[p]) for p in range(world)]
-    recv_sizes = [sum(size[(dx, dy)] for (_, _, dx, dy) in recv[p]) for p in range(world)]
-    sbuf, rbuf = engine.empty(sum(send_sizes)), engine.empty(sum(recv_sizes))
-    off = 0
-    for p in range(world):
-        for (ix, iy, dx, dy) in send[p]:
-            n = size[(dx, dy)]
-            engine.pack_halo(ix + dx, iy + dy, dx, dy, sbuf[off:off + n])
-            off += n
-    if world > 1:
-        if sbuf.is_cuda:
-            torch.cuda.synchronize()              # the engine packed on its own stream; the collective runs on torch's
-        dist.all_to_all_single(rbuf[:sum(recv_sizes)], sbuf[:sum(send_sizes)], recv_sizes, send_sizes, group=group)
-        if rbuf.is_cuda:
-            torch.cuda.synchronize()              # ... and the engine reads rbuf on its own stream: the bytes must have landed
-    halos = {}
-    off = 0
-    for p in range(world):
-        for (ix, iy, dx, dy) in recv[p]:
-            n = size[(dx, dy)]
-            halos.setdefault((ix, iy), [None] * 9)[3 * (dy + 1) + (dx + 1)] = rbuf[off:off + n]
-            off += n
-    return halos, rbuf
-
-
-def blend_all(engine, group=None, raw=False):
-    """Distributed draw()-time refresh: every rank blends the tiles it owns, with the strips of
-    neighbours that live elsewhere.  Returns {(ix,iy): 256x256x3 array}."""
-    halos, keep = exchange_halos(engine, group)
-    out = {}
-    for (ix, iy) in engine.tiles():
-        out[(ix, iy)] = engine.blend_with_halo(ix, iy, halos.get((ix, iy), [None] * 9), raw=raw)
-    del keep
-    return out
-
-
-def gather_tiles(engine, dst_engine=None, root=0, group=None):
-    """save()'s gather: every tile travels once to `root`, which imports it into dst_engine
-    (its own map) -- afterwards root.save() is the reference's whole-mosaic collapse."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    lists = all_tile_lists(engine, group)
-    nb = engine.tile_bytes()
-    if rank != root:
-        mine = sorted(tuple(t) for t in lists[rank])
-        buf = engine.empty(nb * len(mine))
-        for k, (ix, iy) in enumerate(mine):
-            engine.export_tile(ix, iy, buf[k * nb:(k + 1) * nb])
-        if len(mine):
-            if buf.is_cuda:
-                torch.cuda.synchronize()
-            dist.send(buf[:nb * len(mine)], dst=root, group=group)
-        return 0
-    n = 0
-    for p in range(world):
-        if p == root:
-            continue
-        theirs = sorted(tuple(t) for t in lists[p])
-        if not theirs:
-            continue
-        buf = engine.empty(nb * len(theirs))
-        dist.recv(buf[:nb * len(theirs)], src=p, group=group)
-        if buf.is_cuda:
-            torch.cuda.synchronize()              # import_tile reads buf on the engine's stream
-        for k, (ix, iy) in enumerate(theirs):
-            (dst_engine or engine).import_tile(ix, iy, buf[k * nb:(k + 1) * nb])
-            n += 1
-    return n
+def plan_blend(lists, caps, me, high_quality, halo_bytes9):
+    """The library's plan of one pf_dist_blend_changed call (csrc/dist.cpp plan_blend through pf_dist_plan_blend).
+    lists[r] = [(ix, iy, changed), ...] of rank r; returns (send, recv, mine): lists of dicts / tile coordinates."""
+    L = _pkg().lib()
+    n = len(lists)
+    counts = (C.c_int * n)(*[len(l) for l in lists])
+    flat = [v for l in lists for t in l for v in (int(t[0]), int(t[1]), int(t[2]))]
+    recs = (C.c_int * max(len(flat), 1))(*flat)
+    cp = (C.c_longlong * n)(*[int(c) for c in caps])
+    hb = (C.c_size_t * 9)(*[int(b) for b in halo_bytes9])
+    ns, nr, nm = C.c_int(), C.c_int(), C.c_int()
+    L.pf_dist_plan_blend(n, me, counts, recs, cp, 1 if high_quality else 0, hb, None, 0, C.byref(ns), None, 0, C.byref(nr), None, 0, C.byref(nm))
+    send = (StripPlan * max(ns.value, 1))(); recv = (StripPlan * max(nr.value, 1))(); mine = (C.c_int * max(2 * nm.value, 1))()
+    ok = L.pf_dist_plan_blend(n, me, counts, recs, cp, 1 if high_quality else 0, hb, send, ns.value, C.byref(ns),
+                              recv, nr.value, C.byref(nr), mine, nm.value, C.byref(nm))
+    if not ok:
+        raise RuntimeError("pf_dist_plan_blend failed")
+    rec = lambda q: {k: getattr(q, k) for k, _ in StripPlan._fields_}
+    return ([rec(send[i]) for i in range(ns.value)], [rec(recv[i]) for i in range(nr.value)],
+            [(mine[2 * i], mine[2 * i + 1]) for i in range(nm.value)])

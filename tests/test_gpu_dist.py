@@ -117,6 +117,140 @@ def test_dist_draw_and_save_ranks_as_threads(pf, orc, world, force_float, hq):
         d.close()
 
 
+def collective(world, rv, fn):
+    """run fn(rank) on `world` threads (ranks of the in-process rendezvous); returns the per-rank results"""
+    out = [None] * world
+
+    def main(r):
+        try:
+            out[r] = fn(r)
+        except Exception as e:                              # a dead rank would leave the others at the barrier
+            out[r] = e
+            rv.bar.abort()
+    th = [threading.Thread(target=main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]; [t.join(600) for t in th]
+    for r in range(world):
+        assert not isinstance(out[r], Exception), out[r]
+    return out
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_dist_seven_bands(pf, orc, force_float):
+    """BASELINE.json configs[4]'s band count on small frames: with 7 bands the level-0 strips are 128 pixels wide (half a
+    tile) and the coarsest strips one pixel; three ranks, every exchanged byte hashed on both ends (pf_dist_set_verify),
+    draw() and save() against the oracle (Ele::blend .cpp:93-126, save .cpp:806-836)."""
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam, poses, frames = workload(wl)
+    world = 3
+    o = orc.OracleMap(band_num=7, force_float=force_float, scale=2.0)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    maps = [pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, band_number=7, scale=2.0,
+                            shard_rank=r, shard_count=world, shard_block=1) for r in range(world)]
+    for m in maps:
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    for f, p in zip(frames, poses):
+        assert o.feed(f, p)
+        for m in maps:
+            assert m.feed(f, p)
+    rv = Rendezvous(world)
+    dms = [sh.DistMap(m, r, world, backend="host", exchange=rv.fn(r)) for r, m in enumerate(maps)]
+    for d in dms:
+        d.set_verify(True)
+
+    def rank_main(r):
+        coords, px = dms[r].blend_changed()
+        st = dms[r].stats()
+        return {"coords": coords, "px": px, "stats": st, "save": dms[r].save_to_memory(), "save_stats": dms[r].stats()}
+    out = collective(world, rv, rank_main)
+    seen = {}
+    for r in range(world):
+        for t, im in zip(out[r]["coords"], out[r]["px"]):
+            assert pf.tile_owner(maps[r].opt, *t) == r and t not in seen
+            seen[t] = im
+    assert set(seen) == set(o.tiles())
+    for t, im in seen.items():
+        assert np.array_equal(im, o.blend_tile(*t)), "tile %s differs from the oracle's blend" % (t,)
+    assert sum(out[r]["stats"]["bytes_received"] for r in range(world)) > 0
+    assert all(out[r]["stats"]["verified"] == 1 for r in range(world))          # the strip exchange was hashed on both ends
+    assert all(out[r]["save_stats"]["verified"] == 1 for r in range(world))     # ... and the tile gather
+    ref, org = o.save()
+    got = out[0]["save"]
+    assert got is not None and got[1] == org and np.array_equal(got[0], ref)
+    for d in dms:
+        d.close()
+
+
+@pytest.mark.parametrize("world,force_float", [(4, 1), (8, 0)])
+def test_dist_seam_exchange_at_cfg2_size(pf, orc, world, force_float):
+    """BASELINE.json configs[2] at its frame size: 40 keyframes of the 4000x3000 sortie, tiles split over 4 / 8 ranks
+    (threads, host-buffer transport, one GPU, hash cell 2 tiles).  draw() of every tile across ranks and the gathered save()
+    must equal the unsharded HIP map's (itself oracle-checked in test_gpu_at_size.py / test_gpu_steady_state.py); eight
+    probe tiles with neighbours on other ranks are compared with the oracle's Ele::blend directly."""
+    torch = pytest.importorskip("torch")
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam = [4000, 3000, 3000, 3000, 2000, 1500]
+    n = 40
+    poses = wl.serpentine(cam, 100.0, n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(99)
+    frames = [torch.randint(0, 256, (3000, 4000, 3), dtype=torch.uint8, device="cuda", generator=gen) for _ in range(3)]
+    torch.cuda.synchronize()
+
+    def build(**kw):
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, **kw)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+        for k, p in enumerate(poses):
+            assert m.feed_device(frames[k % 3].data_ptr(), 3000, 4000, p)
+        assert m.sync()
+        return m
+    ref = build()
+    maps = [build(shard_rank=r, shard_count=world, shard_block=2) for r in range(world)]
+    tiles = ref.tiles()
+    assert sorted(sum((m.tiles() for m in maps), [])) == sorted(tiles) and len(tiles) > 500
+    assert all(len(m.tiles()) > 0 for m in maps)
+    rv = Rendezvous(world)
+    dms = [sh.DistMap(m, r, world, backend="host", exchange=rv.fn(r)) for r, m in enumerate(maps)]
+
+    def rank_main(r):
+        coords, px = dms[r].blend_changed()
+        st = dms[r].stats()
+        return {"coords": coords, "px": px, "stats": st, "save": dms[r].save_to_memory()}
+    out = collective(world, rv, rank_main)
+    want_xy, want_px = ref.blend_changed(cap=len(tiles))
+    want = {t: want_px[i] for i, t in enumerate(want_xy)}
+    assert set(want) == set(tiles)
+    n_seen, moved = 0, 0
+    for r in range(world):
+        moved += out[r]["stats"]["bytes_received"]
+        for t, im in zip(out[r]["coords"], out[r]["px"]):
+            assert pf.tile_owner(maps[r].opt, *t) == r
+            assert np.array_equal(im, want[t]), "tile %s differs from the unsharded map's blend" % (t,)
+            n_seen += 1
+    assert n_seen == len(tiles) and moved > 100e6              # hundreds of MB of strips crossed ranks
+    got = out[0]["save"]
+    rs = ref.save_to_memory()
+    assert got is not None and got[1] == rs[1] and np.array_equal(got[0], rs[0])
+    del out, want_px, want
+    # probe tiles: full 3x3 neighbourhood, at least one neighbour on another rank -> against the oracle itself
+    owner = {t: pf.tile_owner(maps[0].opt, *t) for t in tiles}
+    ts = set(tiles)
+    probes = [t for t in tiles if all((t[0] + dx, t[1] + dy) in ts for dx in (-1, 0, 1) for dy in (-1, 0, 1))
+              and any(owner[(t[0] + dx, t[1] + dy)] != owner[t] for dx in (-1, 0, 1) for dy in (-1, 0, 1))]
+    probes = probes[::max(1, len(probes) // 8)][:8]
+    assert len(probes) == 8
+    o = orc.OracleMap(force_float=force_float)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+    host = [f.cpu().numpy() for f in frames]
+    for k, p in enumerate(poses):
+        assert o.feed(host[k % 3], p)
+    assert o.tiles() == tiles or sorted(o.tiles()) == sorted(tiles)
+    for t in probes:
+        assert np.array_equal(ref.blend_tile(*t), o.blend_tile(*t)), "probe tile %s: HIP blend differs from the oracle's" % (t,)
+    for d in dms:
+        d.close()
+
+
 def test_dist_caps_and_empty_ranks(pf, orc):
     """a rank may take fewer tiles per call than it has changed (cap), and a rank may hold no tile at all: the providers
     plan with the requester's cap, and the calls repeat until nothing is left"""

@@ -1,9 +1,12 @@
-"""N>1 path on CPU: world_size-2 gloo run of the seam exchange (pi-slam-fusion_amd/sharding.py).
+"""N>1 path on CPU: world_size-2 gloo run of the seam exchange.
 
-The transport and the exchange plan are the product's; the engine behind them is an
-oracle-backed stand-in (no GPU here): each rank holds the tiles the spatial hash gives it.
-Checked against the unsharded oracle: every tile's blend() with strips that crossed ranks,
-and the tile gather that precedes save()."""
+What runs here is the product's: the exchange PLAN is csrc/dist.cpp's plan_blend (through the C ABI,
+pf_dist_plan_blend -- the function DistMap::blend_changed calls), the bytes travel through the product's
+host-buffer hook (sharding.torch_exchange, the pf_exchange_fn the library's HostTransport calls).  Only the pixel
+work (strip pack, 3x3 assembly + collapse) is done by an oracle-backed stand-in, because there is no GPU here; on
+the GPU box tests/test_gpu_dist.py runs the same exchange end to end inside the library.
+Checked against the unsharded oracle: every tile's blend() with strips that crossed ranks, and the tile gather
+that precedes save()."""
 import os
 import socket
 import subprocess
@@ -17,7 +20,8 @@ ELE = 256
 
 
 class OracleEngine:
-    """Exchange interface of sharding.GpuEngine on top of an OracleMap restricted to owned tiles."""
+    """Strip pack / blend / tile export on top of an OracleMap restricted to owned tiles (what FusionMap::pack_strips,
+    blend_tiles and export_tiles do on the GPU)."""
 
     def __init__(self, omap, pf, opt, rank, orc):
         import torch
@@ -106,9 +110,24 @@ class OracleEngine:
         self.imported[(ix, iy)] = bytes(buf.numpy().tobytes())
 
 
+def hook_exchange(sh, send_bufs, recv_sizes, world, rank):
+    """Move per-peer byte strings through the product's pf_exchange_fn (ctypes pointers and sizes, as HostTransport calls it)."""
+    import ctypes as C
+    fn = sh.torch_exchange()
+    keep_s = [(C.c_char * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0") for b in send_bufs]
+    keep_r = [(C.c_char * max(n, 1))() for n in recv_sizes]
+    sp = (C.c_void_p * world)(*[C.addressof(k) for k in keep_s])
+    rp = (C.c_void_p * world)(*[C.addressof(k) for k in keep_r])
+    sb = (C.c_size_t * world)(*[0 if p == rank else len(send_bufs[p]) for p in range(world)])
+    rb = (C.c_size_t * world)(*[0 if p == rank else recv_sizes[p] for p in range(world)])
+    assert fn(None, sp, sb, rp, rb, world) == 1
+    return [bytes(keep_r[p][:recv_sizes[p]]) for p in range(world)]
+
+
 def worker(rank, world, port):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import importlib
+    import torch
     import torch.distributed as dist
     from conftest import load_package
     from helpers import jitter_poses
@@ -128,31 +147,66 @@ def worker(rank, world, port):
     eng = OracleEngine(o, pf, opt, rank, orc)
     all_tiles = o.tiles()
     assert 0 < len(eng.owned) < len(all_tiles)
-    # plan symmetry: what I send to p is what p expects from me
-    lists = sh.all_tile_lists(eng)
-    assert sorted(t for l in lists for t in map(tuple, l)) == sorted(all_tiles)
-    send, recv = sh.plan_halo_exchange(lists, rank)
+    # every rank's tile list on every rank, in the order FusionMap::list_tiles gives (iy, then ix), every tile changed
+    lists = [None] * world
+    dist.all_gather_object(lists, [(ix, iy, 1) for (ix, iy) in sorted(eng.owned, key=lambda t: (t[1], t[0]))])
+    assert sorted((t[0], t[1]) for l in lists for t in l) == sorted(all_tiles)
+    hb9 = [0 if j == 4 else eng.halo_bytes(j % 3 - 1, j // 3 - 1) for j in range(9)]
+    caps = [len(l) for l in lists]
+    send, recv, mine = sh.plan_blend(lists, caps, rank, True, hb9)        # the library's plan
+    assert mine == [(t[0], t[1]) for t in lists[rank]]
+    # plan symmetry: what I send to p, strip for strip and byte for byte, is what p expects from me
     for p in range(world):
-        s_p, r_p = sh.plan_halo_exchange(lists, p)
-        assert send[p] == r_p[rank] and recv[p] == s_p[rank]
+        s_p, r_p, _ = sh.plan_blend(lists, caps, p, True, hb9)
+        mine_to_p = [(q["ix"], q["iy"], q["dx"], q["dy"], q["offset"]) for q in send if q["peer"] == p]
+        p_from_me = [(q["ix"] + q["dx"], q["iy"] + q["dy"], q["dx"], q["dy"], q["offset"]) for q in r_p if q["peer"] == rank]
+        assert mine_to_p == p_from_me
+    # pack what the plan asks of this rank, move it through the product's exchange hook
+    send_bufs = [bytearray() for _ in range(world)]
+    for q in send:
+        assert len(send_bufs[q["peer"]]) == q["offset"]
+        buf = torch.empty(hb9[3 * (q["dy"] + 1) + (q["dx"] + 1)], dtype=torch.uint8)
+        eng.pack_halo(q["ix"], q["iy"], q["dx"], q["dy"], buf)
+        send_bufs[q["peer"]] += buf.numpy().tobytes()
+    recv_sizes = [0] * world
+    for q in recv:
+        recv_sizes[q["peer"]] = max(recv_sizes[q["peer"]], q["offset"] + hb9[3 * (q["dy"] + 1) + (q["dx"] + 1)])
+    got = hook_exchange(sh, [bytes(b) for b in send_bufs], recv_sizes, world, rank)
+    halos = {}
+    for q in recv:
+        j = 3 * (q["dy"] + 1) + (q["dx"] + 1)
+        halos.setdefault((q["ix"], q["iy"]), [None] * 9)[j] = torch.frombuffer(bytearray(got[q["peer"]][q["offset"]:q["offset"] + hb9[j]]), dtype=torch.uint8)
     # blend with remote strips == unsharded oracle blend
-    out = sh.blend_all(eng, raw=True)
     n_remote = 0
-    for (ix, iy), img in out.items():
+    for (ix, iy) in mine:
         full = all((ix + dx, iy + dy) in all_tiles for dx in (-1, 0, 1) for dy in (-1, 0, 1))
-        if full:
-            n_remote += any((ix + dx, iy + dy) not in eng.owned for dx in (-1, 0, 1) for dy in (-1, 0, 1))
-            assert np.array_equal(img, o.blend_tile_raw(ix, iy)), (rank, ix, iy)
+        if not full:
+            assert (ix, iy) not in halos                      # blends alone (.cpp:134-145): the plan moves nothing for it
+            continue
+        img = eng.blend_with_halo(ix, iy, halos.get((ix, iy), [None] * 9), raw=True)
+        n_remote += any((ix + dx, iy + dy) not in eng.owned for dx in (-1, 0, 1) for dy in (-1, 0, 1))
+        assert np.array_equal(img, o.blend_tile_raw(ix, iy)), (rank, ix, iy)
     cnt = [None] * world
     dist.all_gather_object(cnt, n_remote)
     assert sum(cnt) > 0, "no blend needed a remote strip: the test exercises nothing"
-    # save()'s gather
-    got = sh.gather_tiles(eng, root=0)
+    # save()'s gather (DistMap::save_to_memory): every rank's tiles, in list order, once to rank 0
+    nb = eng.tile_bytes()
+    blob = bytearray()
+    if rank != 0:
+        for (ix, iy, _) in lists[rank]:
+            buf = torch.empty(nb, dtype=torch.uint8)
+            eng.export_tile(ix, iy, buf)
+            blob += buf.numpy().tobytes()
+    sizes = [0 if p == 0 or rank != 0 else nb * len(lists[p]) for p in range(world)]
+    got = hook_exchange(sh, [bytes(blob) if p == 0 and rank != 0 else b"" for p in range(world)], sizes, world, rank)
     if rank == 0:
-        assert got == len(all_tiles) - len(eng.owned)
-        for (ix, iy), blob in eng.imported.items():
-            ref = b"".join(a.tobytes() for i in range(o.num_levels) for a in o.tile_level(ix, iy, i))
-            assert blob == ref
+        n = 0
+        for p in range(1, world):
+            for k, (ix, iy, _) in enumerate(lists[p]):
+                ref = b"".join(a.tobytes() for i in range(o.num_levels) for a in o.tile_level(ix, iy, i))
+                assert got[p][k * nb:(k + 1) * nb] == ref
+                n += 1
+        assert n == len(all_tiles) - len(eng.owned)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -168,22 +222,34 @@ def test_seam_exchange_world2_gloo():
 
 
 def test_plan_is_deterministic_and_complete(pf):
+    """The library's plan on a 7x5 tile field split three ways: every strip crosses ranks, every cross-rank neighbour of
+    a tile with a full 3x3 neighbourhood is served exactly once, both sides agree on order and offsets, caps are honoured."""
     import importlib
     sh = importlib.import_module("pi_slam_fusion_amd.sharding")
     opt = pf.default_options(shard_count=3, shard_block=2)
-    tiles = [(x, y) for x in range(-3, 4) for y in range(-2, 3)]
-    lists = [[t for t in tiles if pf.tile_owner(opt, *t) == r] for r in range(3)]
+    tiles = sorted([(x, y) for x in range(-3, 4) for y in range(-2, 3)], key=lambda t: (t[1], t[0]))
+    lists = [[(t[0], t[1], 1) for t in tiles if pf.tile_owner(opt, *t) == r] for r in range(3)]
+    hb9 = [0 if j == 4 else 100 + j for j in range(9)]
+    plans = [sh.plan_blend(lists, [len(l) for l in lists], r, True, hb9) for r in range(3)]
     total = 0
-    for r in range(3):
-        send, recv = sh.plan_halo_exchange(lists, r)
-        assert send[r] == [] and recv[r] == []
+    for r, (send, recv, mine) in enumerate(plans):
+        assert all(q["peer"] != r for q in send + recv)
+        for q in recv:
+            assert (q["ix"], q["iy"], 1) in lists[r] and (q["ix"] + q["dx"], q["iy"] + q["dy"], 1) in lists[q["peer"]]
         for p in range(3):
-            for (ix, iy, dx, dy) in recv[p]:
-                assert (ix, iy) in lists[r] and (ix + dx, iy + dy) in lists[p]
-            total += len(recv[p])
-    want = sum(1 for (x, y) in tiles for dx in (-1, 0, 1) for dy in (-1, 0, 1)
-               if (x + dx, y + dy) in tiles and pf.tile_owner(opt, x, y) != pf.tile_owner(opt, x + dx, y + dy))
-    assert total == want
+            a = [(q["ix"], q["iy"], q["dx"], q["dy"], q["offset"]) for q in send if q["peer"] == p]
+            b = [(q["ix"] + q["dx"], q["iy"] + q["dy"], q["dx"], q["dy"], q["offset"]) for q in plans[p][1] if q["peer"] == r]
+            assert a == b
+        total += len(recv)
+    full = lambda x, y: all((x + dx, y + dy) in tiles for dx in (-1, 0, 1) for dy in (-1, 0, 1))
+    want = sum(1 for (x, y) in tiles if full(x, y) for dx in (-1, 0, 1) for dy in (-1, 0, 1)
+               if pf.tile_owner(opt, x, y) != pf.tile_owner(opt, x + dx, y + dy))
+    assert total == want > 0
+    # low-quality show: every tile blends alone, nothing moves; a cap cuts the requester's list on every rank alike
+    assert all(sh.plan_blend(lists, [len(l) for l in lists], r, False, hb9)[:2] == ([], []) for r in range(3))
+    capped = [sh.plan_blend(lists, [2, 2, 2], r, True, hb9) for r in range(3)]
+    assert all(len(c[2]) == min(2, len(lists[r])) for r, c in enumerate(capped))
+    assert sum(len(c[0]) for c in capped) == sum(len(c[1]) for c in capped)
 
 
 if __name__ == "__main__":
