@@ -228,6 +228,13 @@ int     pf_profile_reset(pf_map* m);
 /* sharding overhead since creation: {frames that put pixels on this rank, level-0 pixels computed (owned tiles + pyramid
  * halo, fused path), tile pixels owned in those frames, tiles held}: [1]/[2] is the halo recompute factor of a shard  */
 int     pf_render_stats(pf_map* m, double out4[4]);
+/* Host section timers with the reference's section names (pi::timer.enter / leave, PIL/src/base/time/Timer.h:43-85;
+ * MultiBandMap2DCPU.cpp:476,555,563,602,628-630,722,742): "Map2D::feed", "MultiBandMap2DCPU::renderFrame",
+ * "MultiBandMap2DCPU::Apply", "MultiBandMap2DCPU::spreadMap", "MultiBandMap2DCPU::updateTexture",
+ * "MultiBandMap2DCPU::save" -- calls, mean / min / max seconds of HOST time per section (kernels run asynchronously: device
+ * time is pf_profile_read's).  With PF_ROCTX=1 in the environment every section is also a roctx range.  Returns the count. */
+int     pf_timer_read(pf_map* m, int cap, const char** names, long long* calls, double* mean_s, double* min_s, double* max_s);
+int     pf_timer_reset(pf_map* m);
 /* frames rendered / rejected since creation */
 int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
 /* Allocator hint, no reference counterpart (MultiBandMap2DCPUEle's cv::Mat tiles, MultiBandMap2DCPU.h:32-51,

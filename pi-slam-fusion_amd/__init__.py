@@ -121,6 +121,8 @@ def lib():
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
     L.pf_render_stats.argtypes = [vp, dp]
+    L.pf_timer_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp, dp]
+    L.pf_timer_reset.argtypes = [vp]
     _lib = L
     return L
 
@@ -360,6 +362,16 @@ class Map2D:
         o = (C.c_double * 4)()
         lib().pf_render_stats(self._h, o)
         return {"frames_with_pixels": int(o[0]), "level0_px": o[1], "owned_px": o[2], "tiles_held": int(o[3])}
+
+    def timers(self):
+        """host section timers under the reference's section names (pi::timer): {name: {calls, mean_s, min_s, max_s}}"""
+        cap = 16
+        names = (C.c_char_p * cap)(); calls = (C.c_longlong * cap)(); mean = (C.c_double * cap)(); mn = (C.c_double * cap)(); mx = (C.c_double * cap)()
+        k = lib().pf_timer_read(self._h, cap, names, calls, mean, mn, mx)
+        return {names[i].decode(): {"calls": calls[i], "mean_s": mean[i], "min_s": mn[i], "max_s": mx[i]} for i in range(k)}
+
+    def timer_reset(self):
+        lib().pf_timer_reset(self._h)
 
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

@@ -182,5 +182,10 @@ int pf_profile_reset(pf_map* m) { if (!m) return 0; m->impl.profile_reset(); ret
 int pf_reserve_tiles(pf_map* m, long long n_tiles) { return m && m->impl.reserve_tiles(n_tiles) ? 1 : 0; }
 int pf_render_stats(pf_map* m, double out4[4]) { if (!m || !out4) return 0; m->impl.render_stats(out4); return 1; }
 int pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped) { if (!m) return 0; m->impl.stats(rendered, rejected, dropped); return 1; }
+int pf_timer_read(pf_map* m, int cap, const char** names, long long* calls, double* mean_s, double* min_s, double* max_s)
+{
+    return m ? m->impl.timer_read(cap, names, calls, mean_s, min_s, max_s) : 0;
+}
+int pf_timer_reset(pf_map* m) { if (!m) return 0; m->impl.timer_reset(); return 1; }
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <dlfcn.h>
 
 namespace pf {
 
@@ -33,6 +35,64 @@ int tile_owner(int shard_count, int shard_block, int ix, int iy)
     const uint32_t h = (cx * 73856093u) ^ (cy * 19349663u);
     return (int)(h % (uint32_t)shard_count);
 }
+
+// --------------------------------------------------------------- sections
+const char* section_name(int id)
+{
+    static const char* n[T_COUNT] = { "Map2D::feed", "MultiBandMap2DCPU::renderFrame", "MultiBandMap2DCPU::Apply",
+                                      "MultiBandMap2DCPU::spreadMap", "MultiBandMap2DCPU::updateTexture", "MultiBandMap2DCPU::save" };
+    return (id >= 0 && id < T_COUNT) ? n[id] : "?";
+}
+
+// roctx ranges (libroctx64 is looked up at run time, only when PF_ROCTX is set)
+namespace {
+struct Roctx { bool tried = false; int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+Roctx g_roctx;
+void roctx_load()
+{
+    g_roctx.tried = true;
+    if (!std::getenv("PF_ROCTX")) return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { std::fprintf(stderr, "pifusion: PF_ROCTX set but no roctx library found\n"); return; }
+    *(void**)&g_roctx.push = dlsym(h, "roctxRangePushA");
+    *(void**)&g_roctx.pop = dlsym(h, "roctxRangePop");
+}
+}  // namespace
+void roctx_push(const char* name) { if (!g_roctx.tried) roctx_load(); if (g_roctx.push) g_roctx.push(name); }
+void roctx_pop() { if (g_roctx.pop) g_roctx.pop(); }
+
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+FusionMap::Section::Section(FusionMap* m_, int id_) : m(m_), id(id_), t0(now_s()) { roctx_push(section_name(id)); }
+FusionMap::Section::~Section()
+{
+    roctx_pop();
+    const double dt = now_s() - t0;
+    std::lock_guard<std::mutex> l(m->timer_mu_);
+    SectionRec& r = m->sections_[id];
+    if (!r.n_calls || dt < r.min_t) r.min_t = dt;
+    if (dt > r.max_t) r.max_t = dt;
+    r.total_t += dt; r.n_calls++;
+}
+
+int FusionMap::timer_read(int cap, const char** names, long long* calls, double* mean_s, double* min_s, double* max_s)
+{
+    std::lock_guard<std::mutex> l(timer_mu_);
+    int n = 0;
+    for (int i = 0; i < T_COUNT && n < cap; i++, n++) {
+        const SectionRec& r = sections_[i];
+        if (names) names[n] = section_name(i);
+        if (calls) calls[n] = r.n_calls;
+        if (mean_s) mean_s[n] = r.n_calls ? r.total_t / r.n_calls : 0;
+        if (min_s) min_s[n] = r.min_t;
+        if (max_s) max_s[n] = r.max_t;
+    }
+    return n;
+}
+
+void FusionMap::timer_reset() { std::lock_guard<std::mutex> l(timer_mu_); for (auto& r : sections_) r = SectionRec(); }
 
 // ------------------------------------------------------------------ store
 Tile* TileStore::find(int ix, int iy)
@@ -391,6 +451,7 @@ bool FusionMap::upload(const pf_image* img, int slot)
 bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr)
 {
     if (!init_ok_) { set_error("feed: no device"); return false; }
+    Section sec(this, T_FEED);
     QueuedFrame f{};
     {
         std::lock_guard<std::mutex> l(mu_);
@@ -498,6 +559,7 @@ bool FusionMap::sync()
 // stable coordinates, so nothing is re-laid out.
 bool FusionMap::spread_map(double xmin, double ymin, double xmax, double ymax)
 {
+    Section sec(this, T_SPREAD);
     int xminInt = (int)std::floor((xmin - min_[0]) * ele_size_inv_);
     int yminInt = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
     int xmaxInt = (int)std::ceil((xmax - min_[0]) * ele_size_inv_);
@@ -515,6 +577,7 @@ bool FusionMap::spread_map(double xmin, double ymin, double xmax, double ymax)
 // ------------------------------------------------------------ renderFrame
 bool FusionMap::render_frame(const QueuedFrame& f)
 {
+    Section sec(this, T_RENDER);
     // 1. pose -> ground points (.cpp:324-347)
     double pts[8];
     if (!footprint(cam_, f.pose, pts)) { n_rejected_++; return false; }
@@ -558,6 +621,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // One pass over the canvas tiles (Apply's tile loop, .cpp:478-492): the tiles this shard owns, their bounding box,
     // the hash cells they fall in (for the need rectangles below) and the table entries: slot address | fresh bit.
     // The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
+    Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
     const bool sharded = opt_.shard_count > 1;
     struct Cell { int cx, cy, x0, y0, x1, y1; };
     Cell cells[64]; int ncells = 0; bool cells_overflow = false;
@@ -1111,6 +1175,7 @@ bool FusionMap::blend_tiles(const std::vector<std::pair<int, int>>& tiles, const
 // come back in ONE device-to-host copy each.
 bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host)
 {
+    Section sec(this, T_UPDATE_TEXTURE);
     const int nl = band_num_ + 1, L = band_num_;
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     const size_t tile_px = (size_t)kElePixels * kElePixels;
@@ -1252,6 +1317,7 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     std::lock_guard<std::mutex> l(mu_);
     if (!init_ok_ || !valid_ || !set_device()) return false;
     if (w_ == 0 || h_ == 0) return false;
+    Section sec(this, T_SAVE);
     int mnx = 1000000, mny = 1000000, mxx = -1000000, mxy = -1000000, cnt = 0;
     store_.for_each([&](int ix, int iy, Tile& t) {
         if (t.fresh) return;

@@ -71,6 +71,15 @@ struct QueuedFrame {
     Pose   pose;            // plane coordinates
 };
 
+// Named host sections, after pi::Timer (PIL/src/base/time/Timer.h:43-85: enter / leave, calls, min / max / mean per
+// section) with the reference's own section names (MultiBandMap2DCPU.cpp:476,555,563,602,628-630,722,742); each section is
+// also a roctx range when PF_ROCTX=1 (rocprofv3 --marker-trace shows them next to the kernels).
+enum SectionId { T_FEED = 0, T_RENDER, T_APPLY, T_SPREAD, T_UPDATE_TEXTURE, T_SAVE, T_COUNT };
+const char* section_name(int id);
+struct SectionRec { long long n_calls = 0; double min_t = 0, max_t = 0, total_t = 0; };
+void roctx_push(const char* name);
+void roctx_pop();
+
 class FusionMap {
 public:
     FusionMap(int type, bool thread, const pf_options& opt);
@@ -118,6 +127,13 @@ public:
     void profile_reset();
     void stats(long long* rendered, long long* rejected, long long* dropped);
     void render_stats(double out[4]);
+    int  timer_read(int cap, const char** names, long long* calls, double* mean_s, double* min_s, double* max_s);
+    void timer_reset();
+    struct Section {            // scope guard: enter on construction, leave on destruction
+        FusionMap* m; int id; double t0;
+        Section(FusionMap* m_, int id_);
+        ~Section();
+    };
     bool reserve_tiles(long long n_tiles);
     const pf_options& options() const { return opt_; }
 
@@ -220,6 +236,8 @@ private:
     std::vector<hipEvent_t> ev_pool_;
     double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};
     ProfRec prof_cur_{};
+    SectionRec sections_[T_COUNT];
+    std::mutex timer_mu_;
     long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0, n_with_pixels_ = 0;
     double px_level0_ = 0, px_owned_ = 0;           // level-0 pixels computed (with halo) / tile pixels owned, over the frames rendered
 };

@@ -6,11 +6,35 @@
 #include <GSLAM/core/SE3.h>
 #endif
 #include <pifusion/Map2D.h>
+#include <pifusion/DataTrans.h>
 #include <cstdio>
+#include <thread>
 #include <vector>
+
+// the tracker -> fusion queue (src/DataTrans.h:40-83): capacity 30, the oldest element is dropped, consumption blocks
+static int datatrans_check()
+{
+    typedef DataTrans<std::pair<int, pi::SE3d> > Wire;
+    Wire& w = Wire::Instance();
+    if (&w != &Wire::Instance()) return 20;                      // singleton per payload type
+    for (int k = 0; k < 35; k++) w.product(std::make_pair(k, pi::SE3d(k, 0, -100, 0, 0, 0, 1)));
+    if (w.size() != 30 || w.dropped() != 5) return 21;
+    std::pair<int, pi::SE3d> v;
+    w.consumption(v);
+    if (v.first != 5) return 22;                                 // 0..4 were dropped
+    while (w.size()) w.consumption(v);
+    if (v.first != 34) return 23;
+    int got = -1;
+    std::thread consumer([&] { std::pair<int, pi::SE3d> q; w.consumption(q); got = q.first; });   // blocks until the product below
+    std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    w.product(std::make_pair(77, pi::SE3d()));
+    consumer.join();
+    return got == 77 ? 0 : 24;
+}
 
 int main()
 {
+    if (int rc = datatrans_check()) { std::printf("DataTrans check failed: %d\n", rc); return rc; }
     std::shared_ptr<Map2D> none = Map2D::create(Map2D::NoType, false);
     if (none) return 2;                                  // Map2D.cpp:53
     std::shared_ptr<Map2D> map = Map2D::create(Map2D::TypeMultiBandCPU, false);

@@ -15,7 +15,7 @@ def build(tmp, extra):
     lib = os.path.join(ROOT, "pi-slam-fusion_amd")
     cmd = ["g++", "-std=c++11", "-O1", "-I" + os.path.join(ROOT, "include")] + extra + [
         os.path.join(ROOT, "tests", "cpp", "header_smoke.cpp"), "-o", exe,
-        "-L" + lib, "-l:libpifusion.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+        "-L" + lib, "-l:libpifusion.so", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     return exe
 
