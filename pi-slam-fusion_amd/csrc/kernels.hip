@@ -17,6 +17,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace pf {
 
@@ -317,6 +318,10 @@ struct FusedWarp {
     // LDS-staged source patch (k_levels<..., PATCH = true>, see patch_plan): a level-0 block stages the part of the frame
     // and of the weight plane its 71x39 warped pixels read -- source rectangle [c - h, c + h + 1] around the image c of the
     // block's centre -- with coalesced 16-byte loads; the bilinear taps and the weight then come from LDS.
+    // radial weight evaluated in the kernel instead of gathered from the plane (k_levels<..., WA = true>): weightImage's
+    // formula (MultiBandMap2DCPU.cpp:403-417) with a correctly rounded square root and quotient, see radial_weight()
+    float  wxc, wyc, wdmax, wrcp;   // x_center, y_center, dis_max, RN(1 / dis_max)
+    int    wtype;                   // Map2D.WeightType
     float  Mf[9];           // M in fp32: only places the patch (a pixel outside it takes the global-memory path)
     int    phx, phy;        // half extents of the patch, source pixels
     int    pitch_i, pitch_w;// LDS row pitches of the frame patch and of the weight patch, bytes (multiples of 16)
@@ -363,8 +368,37 @@ struct WarpTaps {
     uint32_t flags;
 };
 
+// weightImage's entry for source pixel (sx, sy), computed: dis = (sy-yc)^2 + (sx-xc)^2; w = 1 - sqrt(dis) / dis_max
+// (squared for WeightType 1), floored at (float)1e-5 -- every step rounded exactly as the reference's float code rounds it:
+//   * sqrt: v_sqrt_f32 is within 1 ulp; the neighbour test (is the float below / above the better root?) by two exact
+//     fma residuals makes it the correctly rounded root (the compiler's own IEEE sqrt sequence, without its denormal
+//     scaling: dis is 0 or >= 1);
+//   * quotient by the constant dis_max: q0 = s * RN(1/c), exact residual r = s - q0 * c, q = q0 + r * RN(1/c) -- correctly
+//     rounded (Markstein) for q0 within 1 ulp;
+//   * `if (*p <= 1e-5) *p = 1e-5` compares in double and stores (float)1e-5, the float just below 1e-5: that is max(w, 1e-5f).
+// tests: every weight of every parity test is compared bit for bit with the oracle's weightImage gather.
+__device__ __forceinline__ float radial_weight(const FusedWarp& a, int sx, int sy)
+{
+    const float dy = (float)sy - a.wyc, dx = (float)sx - a.wxc;
+    const float dis = __builtin_fmaf(dx, dx, dy * dy);          // both products are exact (|d| < 2^12): one rounding, as dy*dy + dx*dx
+    float s = __builtin_amdgcn_sqrtf(dis);
+    {
+        const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+        const float ed = __builtin_fmaf(-sd, s, dis), eu = __builtin_fmaf(-su, s, dis);
+        s = ed <= 0.f ? sd : s;
+        s = eu > 0.f ? su : s;
+    }
+    const float q0 = s * a.wrcp;
+    const float q = __builtin_fmaf(__builtin_fmaf(-q0, a.wdmax, s), a.wrcp, q0);
+    float w = 1.f - q;
+    if (a.wtype != 0) w = w * w;
+    return fmaxf(w, 1e-5f);
+}
+
 // X0, Y0, W0: the coordinate terms of the pixel's row and 64-wide coordinate block (M0*xb + M1*y + M2 ...), formed by the
 // caller: per pixel (warp_fetch) or once per workgroup in a row table (level3_block, ILP 4)
+// WA: the radial weight is computed (radial_weight) instead of gathered from the weight plane
+template <bool WA = false>
 __device__ __forceinline__ WarpTaps warp_fetch_pre(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col,
                                                    const double X0, const double Y0, const double W0)
 {
@@ -405,8 +439,11 @@ __device__ __forceinline__ WarpTaps warp_fetch_pre(const uint8_t* __restrict__ s
         int sx = Xn, sy = Yn;
         if (!a.plain) { sx = sat_short(sx); sy = sat_short(sy); }
         const bool inb = (unsigned)sx < (unsigned)a.scols && (unsigned)sy < (unsigned)a.srows;
-        const uint32_t woff = inb ? (uint32_t)(__mul24(sy, a.scols) + sx) << 2 : 0u;
-        t.wraw = *(const float*)((const char*)a.wmap + woff);
+        if constexpr (WA) t.wraw = radial_weight(a, sx, sy);
+        else {
+            const uint32_t woff = inb ? (uint32_t)(__mul24(sy, a.scols) + sx) << 2 : 0u;
+            t.wraw = *(const float*)((const char*)a.wmap + woff);
+        }
         flags = inb ? kInb : 0u;
     }
     // one unaligned 8-byte load per source row fetches both taps: pixel "lo" = bytes 0..2, "hi" = bytes cn..cn+2.
@@ -431,9 +468,10 @@ __device__ __forceinline__ WarpTaps warp_fetch_pre(const uint8_t* __restrict__ s
     return t;
 }
 
+template <bool WA = false>
 __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, const FusedWarp& a, const WarpCol& col, int y)
 {
-    return warp_fetch_pre(src, a, col, col.m0xb + a.M[1] * y + a.M[2], col.m3xb + a.M[4] * y + a.M[5], col.m6xb + a.M[7] * y + a.M[8]);
+    return warp_fetch_pre<WA>(src, a, col, col.m0xb + a.M[1] * y + a.M[2], col.m3xb + a.M[4] * y + a.M[5], col.m6xb + a.M[7] * y + a.M[8]);
 }
 
 template <bool F32>
@@ -793,7 +831,7 @@ __device__ __forceinline__ void phase_stamp(unsigned long long* st, int slot)
 // bytes of LDS a PATCH workgroup has behind A for the source patch (Bt lives there after stage A): two workgroups per CU
 constexpr int kPatchBytes = 81920 - 44928;
 
-template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false>
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
 __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
                                              const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
                                              PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table_generic, const int b,
@@ -805,6 +843,12 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     // the table lies in device memory or in the kernel-argument segment: global memory either way (not a FLAT access)
     const uint64_t PF_GLOBAL* __restrict__ table = (const uint64_t PF_GLOBAL*)table_generic;
     if (STAMP) phase_stamp(stamps, 0);
+    // stamped build only: stamp 5 ("stage D done, stores drained") when the function is left, whichever return ends it
+    // (the guard lives at function scope: its destructor runs after stage D, not at the end of an inner block)
+    struct StampExit { unsigned long long* st; __device__ StampExit(unsigned long long* p) : st(p) {} __device__ ~StampExit() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(st, 5); } };
+    struct NoExit { __device__ NoExit(unsigned long long*) {} };
+    typename std::conditional<STAMP, StampExit, NoExit>::type at_exit(stamps);
+    (void)at_exit;
     using T = typename Pix<F32>::T; using WT = typename Pix<F32>::WT;
     using Px = PxT<F32>;
     constexpr int LAH = LBH + 7, LQH = LBH / 2 + 2;
@@ -1001,10 +1045,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     const bool hasb = rb < LAH, hasc = rc < LAH;
                     const int y = row_of(r), yb = row_of(hasb ? rb : r), yc = row_of(hasc ? rc : r);
                     if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; if (hasc) Aat(rc, c) = z; continue; }
-                    const WarpTaps ta = warp_fetch(src, wa, col, y);
-                    const WarpTaps tb = warp_fetch(src, wa, col, yb);
+                    const WarpTaps ta = warp_fetch<WA>(src, wa, col, y);
+                    const WarpTaps tb = warp_fetch<WA>(src, wa, col, yb);
                     if (__builtin_amdgcn_ballot_w64(hasc) != 0) {
-                        const WarpTaps tc = warp_fetch(src, wa, col, yc);
+                        const WarpTaps tc = warp_fetch<WA>(src, wa, col, yc);
                         Aat(r, c) = warp_finish<F32>(ta, wa.cn);
                         if (hasb) Aat(rb, c) = warp_finish<F32>(tb, wa.cn);
                         if (hasc) Aat(rc, c) = warp_finish<F32>(tc, wa.cn);
@@ -1169,11 +1213,6 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     if (g.ablate & 4) return;
 
     // ---- D: 2x2 quad, Laplacian + max-weight select
-    if (STAMP) {
-        // the stamped build ends every path of stage D here
-        struct AtExit { unsigned long long* st; __device__ ~AtExit() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(st, 5); } } at_exit{ stamps };
-        (void)at_exit;
-    }
     if (!ent) return;
     const Px g00 = A[2 * qy + 4][0][qx + 2], g01 = A[2 * qy + 4][1][qx + 2];
     const Px g10 = A[2 * qy + 5][0][qx + 2], g11 = A[2 * qy + 5][1][qx + 2];
@@ -1290,7 +1329,7 @@ struct LevelJob {
 struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
-template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false>
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
 __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? 6 : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
@@ -1329,8 +1368,8 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? 6 : 4) void k_levels(
     }
     unsigned long long* st = nullptr;
     if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
-    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                                   J.table, bb, st, tab0);
+    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH, WA>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
+                                                       J.table, bb, st, tab0);
 }
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1497,6 +1536,16 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     if (wa && !st && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
         if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
         else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        return;
+    }
+    // Default form of the pipelined launch: the radial weight computed in the kernel (radial_weight) -- two gathers per
+    // warped pixel instead of three.  Measured on MI355X (profiles/r03_ab.md): fp32 +1.8 %, int16 +-0 against the weight
+    // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
+    static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
+    if (wa && !wplane && !st && BH == 32 && ilp == 3) {
+        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
+        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
         return;
     }
     if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)

@@ -30,9 +30,14 @@ n = L.pf_debug_phase_stamps(None, 1 << 16)
 buf = np.zeros((n, 8), np.uint64)
 assert L.pf_debug_phase_stamps(buf.ctypes.data, n) == n
 buf = buf[buf[:, 0] > 0]
-t0 = buf[:, 0].min()
 names = ["A (stage + warp)", "wait at barrier 1", "B (pyrDown)", "wait at barrier 2", "D (Laplacian, select, stores drained)"]
-print("%d stamped workgroups; launch span %.1f us at 100 MHz-independent shader clock (ticks %d)" % (len(buf), 0, int(buf[:, 5].max() - t0)))
+# s_memtime counters of different XCDs do not share a base: spans are formed per XCD (stamp slot 7 = XCC id)
+spans = []
+for x in sorted(set(buf[:, 7].astype(int))):
+    bx = buf[buf[:, 7] == x].astype(np.int64)
+    spans.append(int(bx[:, 5].max() - bx[:, 0].min()))
+print("%d stamped workgroups on %d XCDs; launch span per XCD: median %d ticks (min %d, max %d)" %
+      (len(buf), len(spans), int(np.median(spans)), min(spans), max(spans)))
 for job in sorted(set(buf[:, 6].astype(int))):
     b = buf[buf[:, 6] == job].astype(np.int64)
     d = np.diff(b[:, :6], axis=1)
@@ -40,5 +45,9 @@ for job in sorted(set(buf[:, 6].astype(int))):
     print("job %d: %5d workgroups, lifetime mean %7.0f ticks (min %d, max %d)" % (job, len(b), life.mean(), life.min(), life.max()))
     for i, nm in enumerate(names):
         print("    %-40s mean %7.0f  median %7.0f  p90 %7.0f  = %4.1f %% of lifetime" % (nm, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90), 100 * d[:, i].sum() / life.sum()))
-    start = b[:, 0] - t0
-    print("    starts: first %d, median %d, last %d; ends: median %d, last %d" % (start.min(), np.median(start), start.max(), np.median(b[:, 5] - t0), (b[:, 5] - t0).max()))
+    # start / end relative to the first start on the same XCD
+    rel0, rel5 = [], []
+    for x in sorted(set(b[:, 7])):
+        bx = b[b[:, 7] == x]; base = buf[buf[:, 7] == x].astype(np.int64)[:, 0].min()
+        rel0 += list(bx[:, 0] - base); rel5 += list(bx[:, 5] - base)
+    print("    starts (per-XCD base): first %d, median %d, last %d; ends: median %d, last %d" % (min(rel0), np.median(rel0), max(rel0), np.median(rel5), max(rel5)))
