@@ -180,6 +180,13 @@ int      pf_dist_unique_id(void* out128);
 pf_dist* pf_dist_init_rccl(pf_map* m, const void* unique_id128, int rank, int nranks);
 pf_dist* pf_dist_init_host(pf_map* m, int rank, int nranks, pf_exchange_fn fn, void* user);
 void     pf_dist_destroy(pf_dist* d);
+/* Map2D::feed across ranks ("one H2D + P2P over xGMI"): the tracker hands a keyframe to ONE rank -- `root`, the
+ * only rank whose img->data (host pixels) is read; every rank makes the call with the same pose and the same frame
+ * description (rows, cols, type, step).  From the pose alone all ranks derive which ranks own a tile of the frame's canvas;
+ * the root copies the pixels to its GPU once and sends them, in one grouped point-to-point exchange, to exactly those
+ * ranks; each rank then renders its tiles (a rank that holds none of the canvas only advances its grid).  thread=0 maps.
+ * Returns 1 (accepted), 0 (rejected as Map2D::feed would: oblique view ...), -1 (failure, on every rank alike).          */
+int      pf_dist_feed(pf_dist* d, const pf_image* img, const double pose[7], int root);
 /* draw() across ranks: every rank blends ITS changed tiles (at most cap) with the edge strips of neighbours that live on
  * other ranks and clears their Ischanged flags.  One pack launch, one grouped exchange, one batched blend per call.
  * Returns the number of tiles written to xy / bgr (cap tiles of 256x256x3 each), -1 on failure.                     */

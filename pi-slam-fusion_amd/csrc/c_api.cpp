@@ -134,6 +134,7 @@ pf_dist* pf_dist_init_host(pf_map* m, int rank, int nranks, pf_exchange_fn fn, v
 }
 void pf_dist_destroy(pf_dist* d) { delete d; }
 int pf_dist_blend_changed(pf_dist* d, int* xy, uint8_t* bgr, int cap) { return (d && xy && bgr && cap >= 0) ? d->impl.blend_changed(xy, bgr, cap) : -1; }
+int pf_dist_feed(pf_dist* d, const pf_image* img, const double pose[7], int root) { return (d && img && pose) ? d->impl.feed(img, pose, root) : -1; }
 int pf_dist_save(pf_dist* d, const char* filename) { return d && filename && d->impl.save(filename); }
 int pf_dist_save_to_memory(pf_dist* d, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return d && rows && cols && tx0 && ty0 && d->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }

@@ -441,6 +441,42 @@ bool DistMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* 
     return ok;
 }
 
+// Map2D::feed across ranks (SURVEY 8e "one H2D + P2P over xGMI"): the tracker hands its keyframe to ONE rank (`root`,
+// host pixels); every rank makes the call with the same pose and frame description.  All ranks derive, from the pose
+// alone, which ranks own a tile of the frame's canvas; the root copies the pixels to its GPU once and sends them -- one
+// grouped point-to-point exchange -- to exactly those ranks; every rank then renders its tiles (or, holding none of the
+// canvas, only advances its grid).  No rank is fed through its own PCIe link except the root.
+int DistMap::feed(const pf_image* img, const double pose7[7], int root)
+{
+    stats_ = {};
+    if (!img || !m_->use_device()) return -1;
+    const int n = t_->nranks, me = t_->rank;
+    if (root < 0 || root >= n) { set_error("pf_dist_feed: root out of range"); return -1; }
+    std::vector<unsigned char> needs;
+    bool ok_here = m_->frame_needs(pose7, needs) && (int)needs.size() == n;
+    if (ok_here && me == root && !img->data) { set_error("pf_dist_feed: the root has no pixels"); ok_here = false; }
+    bool anyone = false;
+    for (int p = 0; ok_here && p < n; p++) anyone = anyone || (needs[p] && p != root);
+    int slot = -1; void* dev = nullptr; size_t bytes = 0;
+    const bool i_take = ok_here && needs[me], i_send = ok_here && me == root && anyone;
+    if (i_take || i_send) { slot = m_->stage_frame(img, me == root, &dev, &bytes); ok_here = slot >= 0; }
+    if (!agree(ok_here)) { m_->release_staged(slot); return -1; }
+    if (n > 1 && anyone) {
+        std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
+        std::vector<size_t> sb(n, 0), rb(n, 0);
+        if (me == root) { for (int p = 0; p < n; p++) if (p != root && needs[p]) { s[p] = dev; sb[p] = bytes; stats_.bytes_sent += bytes; stats_.peers++; } }
+        else if (needs[me]) { r[root] = dev; rb[root] = bytes; stats_.bytes_received = bytes; stats_.peers = 1; }
+        const auto t0 = std::chrono::steady_clock::now();
+        if (!exchange_checked(s, sb, r, rb, "keyframe")) { m_->release_staged(slot); return -1; }
+        stats_.exchange_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // a root that owns none of the canvas staged the frame only to send it: release the slot through a geometry-only feed
+    const bool rendered = m_->feed_staged(needs[me] ? slot : -1, img, pose7);
+    if (!needs[me] && slot >= 0) m_->release_staged(slot);
+    stats_.tiles = needs[me];
+    return rendered ? 1 : 0;
+}
+
 bool DistMap::save(const char* filename)
 {
     int rows = 0, cols = 0, tx0 = 0, ty0 = 0;

@@ -37,6 +37,7 @@ public:
     int  blend_changed(int* xy, uint8_t* bgr, int cap);        // tiles blended on this rank, -1 on failure
     bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
     bool save(const char* filename);
+    int  feed(const pf_image* img, const double pose7[7], int root);   // 1 rendered / accepted, 0 rejected, -1 failure
     const pf_dist_stats& stats() const { return stats_; }
     const Transport* transport() const { return t_; }
     void set_verify(bool on) { verify_ = on; }

@@ -505,6 +505,66 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
     return render_frame(f);
 }
 
+// ---- frame distribution (pf_dist_feed)
+// The ranks that own at least one tile of the canvas this keyframe renders into.  Same geometry as render_frame
+// (.cpp:324-394); spreadMap is applied here already -- it is idempotent for the render that follows.
+bool FusionMap::frame_needs(const double pose7[7], std::vector<unsigned char>& rank_needs)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    rank_needs.assign((size_t)opt_.shard_count, 0);
+    if (!valid_) return false;
+    const Pose pose = mul(plane_inv_, pose_from7(pose7));
+    double pts[8];
+    if (!footprint(cam_, pose, pts)) return true;            // oblique view: nobody renders it (feed will say false)
+    double xmin = pts[0], xmax = xmin, ymin = pts[1], ymax = ymin;
+    for (int i = 1; i < 4; i++) {
+        xmin = std::min(xmin, pts[2 * i]); xmax = std::max(xmax, pts[2 * i]);
+        ymin = std::min(ymin, pts[2 * i + 1]); ymax = std::max(ymax, pts[2 * i + 1]);
+    }
+    if (xmin < min_[0] || xmax > max_[0] || ymin < min_[1] || ymax > max_[1])
+        if (!spread_map(xmin, ymin, xmax, ymax)) return false;
+    const int x0 = (int)std::floor((xmin - min_[0]) * ele_size_inv_), y0 = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
+    const int x1 = (int)std::ceil((xmax - min_[0]) * ele_size_inv_), y1 = (int)std::ceil((ymax - min_[1]) * ele_size_inv_);
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++)
+            rank_needs[(size_t)tile_owner(opt_.shard_count, opt_.shard_block, x + off_x_, y + off_y_)] = 1;
+    return true;
+}
+
+int FusionMap::stage_frame(const pf_image* desc, bool upload_host, void** dev, size_t* bytes)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !valid_ || !set_device() || thread_) { set_error("stage_frame: needs a prepared thread=0 map"); return -1; }
+    const int cn = desc->type == PF_8UC4 ? 4 : 3;
+    const size_t row = (size_t)desc->cols * cn, step = desc->step ? desc->step : row;
+    if ((desc->type != PF_8UC3 && desc->type != PF_8UC4) || desc->cols != cam_.w || desc->rows != cam_.h || step < row ||
+        step * (size_t)desc->rows >= (1ull << 31)) { set_error("stage_frame: frame does not match the camera"); return -1; }
+    const int slot = acquire_slot((size_t)desc->rows * step);
+    if (slot < 0) return -1;
+    if (upload_host) {
+        if (!desc->data || !upload(desc, slot)) return -1;
+    }
+    slots_[slot].queued = true;                                // held until feed_staged
+    if (dev) *dev = slots_[slot].dev;
+    if (bytes) *bytes = (size_t)(desc->rows - 1) * step + row;
+    return slot;
+}
+
+bool FusionMap::feed_staged(int slot, const pf_image* desc, const double pose7[7])
+{
+    if (!init_ok_) return false;
+    Section sec(this, T_FEED);
+    std::lock_guard<std::mutex> l(mu_);
+    if (slot >= 0) { std::lock_guard<std::mutex> q(qmu_); slots_[slot].queued = false; }
+    if (!valid_ || !set_device()) return false;
+    QueuedFrame f{};
+    f.pose = mul(plane_inv_, pose_from7(pose7));
+    f.slot = slot; f.ext = nullptr;
+    f.rows = desc->rows; f.cols = desc->cols; f.cn = desc->type == PF_8UC4 ? 4 : 3;
+    f.step = desc->step ? (long)desc->step : (long)desc->cols * f.cn;
+    return render_frame(f);
+}
+
 // test hook: the bytes of the most recently uploaded host frame as they lie in HBM
 long FusionMap::read_back_last_frame(void* out, size_t cap)
 {

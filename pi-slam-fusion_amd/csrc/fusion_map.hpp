@@ -102,6 +102,14 @@ public:
     bool pack_strips(const std::vector<StripReq>& reqs, void* dev_out);
     bool export_tiles(const std::vector<std::pair<int, int>>& tiles, void* dev_out);
     bool blend_tiles(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, uint8_t* bgr);
+    // frame distribution support (dist.cpp, pf_dist_feed): which ranks hold a tile of this keyframe's canvas (geometry
+    // only; applies spreadMap exactly as feed() would, so a later feed of the same pose finds the grid as it left it),
+    // a staging slot in HBM for the frame (filled from the host on the root, by the transport elsewhere), and the render
+    // of a staged frame
+    bool frame_needs(const double pose7[7], std::vector<unsigned char>& rank_needs);
+    int  stage_frame(const pf_image* desc, bool upload_host, void** dev, size_t* bytes);     // slot index, -1 on failure
+    bool feed_staged(int slot, const pf_image* desc, const double pose7[7]);                 // slot < 0: geometry-only feed
+    void release_staged(int slot) { std::lock_guard<std::mutex> q(qmu_); if (slot >= 0 && slot < (int)slots_.size()) slots_[slot].queued = false; }
     hipStream_t stream() const { return stream_; }
     int  device() const { return device_; }
     bool use_device() { return set_device(); }

@@ -87,6 +87,21 @@ class DistMap:
         except Exception:
             pass
 
+    def feed(self, img, pose, root=0, shape=None):
+        """Map2D::feed across ranks (pf_dist_feed): `img` (HxWx3/4 uint8, host) is read on `root` only; the other ranks
+        pass None and the frame's shape (rows, cols, channels).  Returns True / False like Map2D.feed."""
+        pf = _pkg()
+        p = np.ascontiguousarray(pose, dtype=np.float64).reshape(-1)
+        if img is not None:
+            img = np.ascontiguousarray(img, dtype=np.uint8)
+            shape = img.shape
+        rows, cols, ch = shape
+        im = pf.Image(rows, cols, pf.PF_8UC3 if ch == 3 else pf.PF_8UC4, img.ctypes.data if img is not None else None, 0)
+        rc = pf.lib().pf_dist_feed(self._h, C.byref(im), p.ctypes.data_as(C.POINTER(C.c_double)), root)
+        if rc < 0:
+            raise RuntimeError("pf_dist_feed failed: %s" % pf.lib().pf_last_error().decode())
+        return bool(rc)
+
     def blend_changed(self, cap=None):
         """draw() across ranks: this rank's changed tiles, blended with remote neighbour strips -> (coords, pixels)"""
         pf = _pkg()

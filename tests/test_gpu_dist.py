@@ -251,6 +251,57 @@ def test_dist_seam_exchange_at_cfg2_size(pf, orc, world, force_float):
         d.close()
 
 
+@pytest.mark.parametrize("world,force_float,root", [(3, 0, 0), (4, 1, 2)])
+def test_dist_feed_from_one_rank(pf, orc, world, force_float, root):
+    """pf_dist_feed: the keyframes live on the host of ONE rank; every rank gets the pose, only the ranks that own a tile
+    of a frame's canvas get its pixels (one grouped exchange from the root's GPU, hashed on both ends here), and the
+    shards' tiles -- union and pixels -- are the oracle's.  Reference: Map2D::feed, MultiBandMap2DCPU.cpp:288-309."""
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam, poses, frames = workload(wl)
+    o = orc.OracleMap(force_float=force_float, scale=2.0)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    maps = [pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, scale=2.0,
+                            shard_rank=r, shard_count=world, shard_block=2) for r in range(world)]
+    for m in maps:
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    rv = Rendezvous(world)
+    dms = [sh.DistMap(m, r, world, backend="host", exchange=rv.fn(r)) for r, m in enumerate(maps)]
+    for d in dms:
+        d.set_verify(True)
+    s80 = np.sin(np.radians(80) / 2), np.cos(np.radians(80) / 2)
+    oblique = [0, 0, -100, s80[0], 0, 0, s80[1]]
+
+    def rank_main(r):
+        moved = 0
+        for f, p in zip(frames, poses):
+            assert dms[r].feed(f if r == root else None, p, root=root, shape=f.shape) is True
+            st = dms[r].stats()
+            moved += st["bytes_received"] + st["bytes_sent"]
+        assert dms[r].feed(frames[0] if r == root else None, oblique, root=root, shape=frames[0].shape) is False   # rejected alike
+        assert maps[r].sync()
+        return moved
+    for f, p in zip(frames, poses):
+        assert o.feed(f, p)
+    out = collective(world, rv, rank_main)
+    from helpers import map_digest
+    want, got = map_digest(o), {}
+    for r, m in enumerate(maps):
+        for t in m.tiles():
+            assert pf.tile_owner(m.opt, *t) == r
+        d = map_digest(m)
+        assert not (set(d) & set(got))
+        got.update(d)
+        assert m.grid() == o.grid()
+    assert got == want
+    nbytes = frames[0].size
+    assert out[root] > 0 and out[root] % nbytes == 0                         # whole frames left the root ...
+    assert sum(out) == 2 * out[root]                                          # ... and every byte sent was received once
+    assert out[root] <= (world - 1) * len(frames) * nbytes                    # at most one copy per other rank and frame (ranks without a tile of the canvas get none)
+    for d in dms:
+        d.close()
+
+
 def test_dist_caps_and_empty_ranks(pf, orc):
     """a rank may take fewer tiles per call than it has changed (cap), and a rank may hold no tile at all: the providers
     plan with the requester's cap, and the calls repeat until nothing is left"""
