@@ -511,9 +511,14 @@ __device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
             const float s = (float)(1. / 255.);
             v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
         }
-        const float tt = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
-        if constexpr (F32) o.c[k] = tt;
-        else o.c[k] = (short)sat_short(__float2int_rn(tt));
+        if constexpr (F32) o.c[k] = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+        else {
+            // int16: taps are integers <= 255 and the weights multiples of 2^-10, so every product and every partial sum is
+            // a multiple of 2^-10 below 2^8 -- exact in fp32 whatever the association, fused or not.  Three fused
+            // multiply-adds give the same bits as the reference's mul/add chain; only the final cvRound rounds.
+            const float tt = __builtin_fmaf(v3, c3, __builtin_fmaf(v2, c2, __builtin_fmaf(v1, c1, v0 * c0)));
+            o.c[k] = (short)sat_short(__float2int_rn(tt));
+        }
     }
     if constexpr (!F32) o.pad = 0;
     return o;
@@ -1387,6 +1392,25 @@ static int plain_homography(const WarpArgs& wa)
 // bounded from the map's behaviour at the canvas corners and centre, two pixels of margin -- that fits the LDS budget.
 // Fills w.Mf / phx / phy / pitch_*.  A pixel that falls outside its block's patch all the same (the bound is an estimate
 // for strongly projective maps) takes the global-memory path inside the kernel: results never depend on this plan.
+// Over the whole canvas plus the 4-pixel halo of the blocks: W of one sign, away from zero, and every source coordinate
+// far inside the int range?  Numerators and W are affine in (x, y), so their extremes over the rectangle are at its corners.
+// 1e7 leaves the kernel's own per-pixel bound (3e7) a wide margin for the block-relative evaluation order.
+static bool tame_canvas(const double* M, int crows, int ccols)
+{
+    const double xs[2] = { -4.0, ccols + 3.0 }, ys[2] = { -4.0, crows + 3.0 };
+    double wmin = 0, nmax = 0; int sign = 0;
+    for (int i = 0; i < 4; i++) {
+        const double x = xs[i & 1], y = ys[i >> 1], W = M[6] * x + M[7] * y + M[8];
+        if (!(std::fabs(W) > 0x1p-400)) return false;
+        const int sg = W > 0 ? 1 : -1;
+        if (sign && sg != sign) return false;
+        sign = sg;
+        wmin = i ? std::min(wmin, std::fabs(W)) : std::fabs(W);
+        nmax = std::max(nmax, std::max(std::fabs(M[0] * x + M[1] * y + M[2]), std::fabs(M[3] * x + M[4] * y + M[5])));
+    }
+    return nmax / wmin < 1.0e7;
+}
+
 static bool patch_plan(const WarpArgs& wa, int crows, int ccols, int block_rows, FusedWarp& w)
 {
     // Measured on MI355X (profiles/r03_patch_stage_a.md): the staged form needs 2 workgroups per CU instead of 3 and is
@@ -1398,19 +1422,7 @@ static bool patch_plan(const WarpArgs& wa, int crows, int ccols, int block_rows,
         W = M[6] * x + M[7] * y + M[8];
         px = (M[0] * x + M[1] * y + M[2]) / W; py = (M[3] * x + M[4] * y + M[5]) / W;
     };
-    const double xs[2] = { -4.0, ccols + 3.0 }, ys[2] = { -4.0, crows + 3.0 };
-    double wmin = 0, nmax = 0; int sign = 0;
-    for (int i = 0; i < 4; i++) {
-        const double x = xs[i & 1], y = ys[i >> 1], W = M[6] * x + M[7] * y + M[8];
-        if (!(std::fabs(W) > 1e-300)) return false;
-        const int sg = W > 0 ? 1 : -1;
-        if (sign && sg != sign) return false;
-        sign = sg;
-        wmin = i ? std::min(wmin, std::fabs(W)) : std::fabs(W);
-        nmax = std::max(nmax, std::max(std::fabs(M[0] * x + M[1] * y + M[2]), std::fabs(M[3] * x + M[4] * y + M[5])));
-    }
-    // numerators and W are affine: their extremes over the rectangle are at its corners; 1e7 leaves the kernel's 3e7 a wide margin
-    if (!(nmax / wmin < 1.0e7) || !(wmin > 0x1p-400) ) return false;
+    if (!tame_canvas(M, crows, ccols)) return false;
     double ex = 0, ey = 0;
     const double cx[5] = { 32.0, ccols - 32.0, 32.0, ccols - 32.0, ccols * 0.5 }, cy[5] = { 16.0, 16.0, crows - 16.0, crows - 16.0, crows * 0.5 };
     for (int k = 0; k < 5; k++) {
