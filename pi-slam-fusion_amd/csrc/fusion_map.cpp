@@ -1046,7 +1046,8 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid
     if (cur) add(*cur, 0);
-    for (int s = 1; s < L; s++) if (pipe_[s].valid) add(pipe_[s], s);
+    static const bool no_upper = std::getenv("PF_NO_UPPER") != nullptr;       // diagnostics (timing only, wrong tiles): what the upper-level jobs add to a launch
+    for (int s = 1; s < L; s++) if (pipe_[s].valid && !no_upper) add(pipe_[s], s);
     if (n) {
         prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_);
         launch_levels(stream_, lay_, jobs, n, wa, src);
