@@ -302,6 +302,15 @@ template <> struct alignas(16) PxT<true>  { float c[3]; float w; };
 template <> struct alignas(4)  PxT<false> { short c[3]; short pad; float w; };
 template <bool F32> struct alignas(16) HxT { typename Pix<F32>::WT c[3]; float w; };
 
+// int16 pyramids, stages B and D in packed 16-bit arithmetic (two channels per instruction).  Exact: Gaussian levels of an
+// 8-bit frame stay in [0, 255], so the 5-tap sums (<= 255*16), their vertical sums (<= 255*256 = 65280, unsigned 16 bits
+// hold it, +128 included), the pyrUp sums (<= 255*64 = 16320) and the Laplacian (|.| <= 255) never leave 16 bits -- the
+// int32 arithmetic of pyramids.cpp gives the same bits ((v+128)>>8, (v+32)>>6, no saturation reached).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short ss2 __attribute__((ext_vector_type(2)));
+struct __attribute__((may_alias)) alignas(4) PxP { us2 c01, c2p; float w; };       // PxT<false> seen as two channel pairs
+struct __attribute__((may_alias)) alignas(4) BxP { ss2 c01, c2p; };                // Bx of the int16 build (c[4])
+
 constexpr int LBW = 64, LAW = LBW + 7, LQW = LBW / 2 + 2;      // block width, staged width, half-size width (+halo)
 
 // per-launch scalars kept small on purpose: the warp stage is SGPR-hungry, and whole TileLayout /
@@ -1171,14 +1180,17 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                 if (j == 6) emit(1);
             }
         } else {
-            int h[7][3]; float hw[7];
+            us2 h01[7], h2p[7]; float hw[7];
             auto emit = [&](int e) {
                 const int p = 2 * pp + e, Y = by0 + p;
                 if (Y < 0 || Y >= nrows) return;
                 Px o;
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    o.c[k] = cast_down(h[2 * e + 2][k] * 6 + (h[2 * e + 1][k] + h[2 * e + 3][k]) * 4 + h[2 * e][k] + h[2 * e + 4][k]);
+                {
+                    const us2 v01 = h01[2 * e + 2] * (us2)6 + (h01[2 * e + 1] + h01[2 * e + 3]) * (us2)4 + h01[2 * e] + h01[2 * e + 4];
+                    const us2 v2p = h2p[2 * e + 2] * (us2)6 + (h2p[2 * e + 1] + h2p[2 * e + 3]) * (us2)4 + h2p[2 * e] + h2p[2 * e + 4];
+                    const us2 o01 = (v01 + (us2)128) >> (us2)8, o2p = (v2p + (us2)128) >> (us2)8;
+                    o.c[0] = (short)o01.x; o.c[1] = (short)o01.y; o.c[2] = (short)o2p.x;
+                }
                 {
                     const float r0 = hw[2 * e], r1 = hw[2 * e + 1], r2 = hw[2 * e + 2], r3 = hw[2 * e + 3], r4 = hw[2 * e + 4];
                     if (X < vec_w) {
@@ -1201,12 +1213,12 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             };
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                const Px* ev = &A[4 * pp + j][0][q]; const Px* od = &A[4 * pp + j][1][q];
-                const Px a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
-#pragma unroll
-                for (int k = 0; k < 3; k++) h[j][k] = (int)a2.c[k] * 6 + ((int)a1.c[k] + (int)a3.c[k]) * 4 + (int)a0.c[k] + (int)a4.c[k];
+                const PxP* ev = reinterpret_cast<const PxP*>(&A[4 * pp + j][0][q]); const PxP* od = reinterpret_cast<const PxP*>(&A[4 * pp + j][1][q]);
+                const PxP a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
+                h01[j] = a2.c01 * (us2)6 + (a1.c01 + a3.c01) * (us2)4 + a0.c01 + a4.c01;
+                h2p[j] = a2.c2p * (us2)6 + (a1.c2p + a3.c2p) * (us2)4 + a0.c2p + a4.c2p;
                 hw[j] = a2.w * 6 + (a1.w + a3.w) * 4 + a0.w + a4.w;
-                asm volatile("" : "+v"(h[j][0]), "+v"(h[j][1]), "+v"(h[j][2]), "+v"(hw[j]) :: "memory");
+                asm volatile("" : "+v"(h01[j]), "+v"(h2p[j]), "+v"(hw[j]) :: "memory");
                 if (j == 4) emit(0);
                 if (j == 6) emit(1);
             }
@@ -1265,6 +1277,28 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             if (s11) { st3(dl + 3 * ts + 3, o11L.x, o11L.y, o11c); dw[ts + 1] = g11.w; }
             return;
         }
+    }
+    if constexpr (!F32) {
+        // int16: packed 16-bit arithmetic, channels (0,1) and (2,pad); the edge forms are the interior form on reflected
+        // (left) / replicated (right) neighbours, which ja / jc already name
+        ss2 he01[3], ho01[3], he2p[3], ho2p[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const BxP a = *reinterpret_cast<const BxP*>(&Bt[rows3[r]][ja]), bq = *reinterpret_cast<const BxP*>(&Bt[rows3[r]][j]),
+                      c = *reinterpret_cast<const BxP*>(&Bt[rows3[r]][jc]);
+            he01[r] = a.c01 + bq.c01 * (ss2)6 + c.c01; ho01[r] = (bq.c01 + c.c01) * (ss2)4;
+            he2p[r] = a.c2p + bq.c2p * (ss2)6 + c.c2p; ho2p[r] = (bq.c2p + c.c2p) * (ss2)4;
+        }
+        auto up_e = [](ss2 u0, ss2 u1, ss2 u2) { return (u0 + u1 * (ss2)6 + u2 + (ss2)32) >> (ss2)6; };
+        auto up_o = [](ss2 u1, ss2 u2) { return ((u1 + u2) * (ss2)4 + (ss2)32) >> (ss2)6; };
+        auto px2 = [](const Px& q, ss2& c01, ss2& c2p) { const PxP& v = reinterpret_cast<const PxP&>(q); c01 = (ss2)v.c01; c2p = (ss2)v.c2p; };
+        ss2 a01, a2p;
+        auto st3p = [&](T PF_GLOBAL* p, ss2 c01, ss2 c2p) { PF_STORE(p, c01.x); PF_STORE(p + 1, c01.y); PF_STORE(p + 2, c2p.x); };
+        if (s00) { px2(g00, a01, a2p); st3p(dl, a01 - up_e(he01[0], he01[1], he01[2]), a2p - up_e(he2p[0], he2p[1], he2p[2])); dw[0] = g00.w; }
+        if (s01) { px2(g01, a01, a2p); st3p(dl + 3, a01 - up_e(ho01[0], ho01[1], ho01[2]), a2p - up_e(ho2p[0], ho2p[1], ho2p[2])); dw[1] = g01.w; }
+        if (s10) { px2(g10, a01, a2p); st3p(dl + 3 * ts, a01 - up_o(he01[1], he01[2]), a2p - up_o(he2p[1], he2p[2])); dw[ts] = g10.w; }
+        if (s11) { px2(g11, a01, a2p); st3p(dl + 3 * ts + 3, a01 - up_o(ho01[1], ho01[2]), a2p - up_o(ho2p[1], ho2p[2])); dw[ts + 1] = g11.w; }
+        return;
     }
     WT he[3][3], ho[3][3];                                   // [row][channel]: even / odd output column
 #pragma unroll
