@@ -31,11 +31,16 @@ def main():
     frames = [wl.smooth_frame(480, 640, k) ^ wl.noise_frame(480, 640, k) for k in range(len(poses))]
     m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=ff, scale=2.0, device=dev, shard_rank=rank, shard_count=world, shard_block=1)
     assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
-    for f, p in zip(frames, poses):
-        assert m.feed(f, p)
     d = sh.DistMap(m, rank, world, backend="nccl" if backend == "nccl" else "host")
+    info = d.info()
+    assert info["nranks"] == world and info["rank"] == rank, info       # what the library's own transport sees
+    d.set_verify(True)                                                   # every exchange hashed on both ends (a first multi-GPU run names the pair that moved wrong bytes)
+    # the keyframes live on rank 0 only: pf_dist_feed moves each to the ranks that own part of its canvas
+    for f, p in zip(frames, poses):
+        assert d.feed(f if rank == 0 else None, p, root=0, shape=f.shape)
     coords, px = d.blend_changed()
     st = d.stats()
+    assert world == 1 or st["verified"] == 1, st
     coords2, _ = d.blend_changed()                       # Ischanged flags were cleared: nothing to do the second time
     saved = d.save_to_memory()
     got = [None] * world
@@ -58,7 +63,7 @@ def main():
         assert seen == set(o.tiles()) and moved > 0
         ref, org = o.save()
         assert saved[1] == org and np.array_equal(saved[0], ref)
-        print("DIST OK backend=%s world=%d float=%d tiles=%d seam_bytes=%d" % (backend, world, ff, len(seen), moved), flush=True)
+        print("DIST OK backend=%s transport=%s world=%d float=%d tiles=%d seam_bytes=%d" % (backend, info["transport"], world, ff, len(seen), moved), flush=True)
     dist.barrier()
     d.close(); m.close()
     dist.destroy_process_group()
