@@ -1082,9 +1082,9 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     else { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
                 }
                 if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
-                const WarpTaps ta = warp_fetch(src, wa, col, y);
+                const WarpTaps ta = warp_fetch<WA>(src, wa, col, y);
                 if (__builtin_amdgcn_ballot_w64(hasb) != 0) {
-                    const WarpTaps tb = warp_fetch(src, wa, col, hasb ? yb : y);
+                    const WarpTaps tb = warp_fetch<WA>(src, wa, col, hasb ? yb : y);
                     Aat(r, c) = warp_finish<F32>(ta, wa.cn);
                     if (hasb) Aat(rb, c) = warp_finish<F32>(tb, wa.cn);
                 } else
@@ -1369,7 +1369,7 @@ struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n; L
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
-__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? 6 : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
+__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ? 8 : 6) : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
     // when there is one) or to the upper-level jobs: last in the grid by default, or (PF_INTERLEAVE_JOBS, diagnostics)
@@ -1567,7 +1567,10 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         w.plain = plain_homography(*wa);
     }
     static const bool stamp = getenv("PF_STAMP") != nullptr;
-    static const int ilp = getenv("PF_A_ILP") ? atoi(getenv("PF_A_ILP")) : 3;       // measured: 3 rows per step +1.2 % over 2 (both pyramid types)
+    // warp rows a thread has in flight per step.  fp32: 3 (+1.2 % over 2, r02).  int16: 2 -- that form fits 64 VGPRs, so FOUR
+    // workgroups share a CU (38.6 KB of LDS each) instead of three: +3.2 % over 3 rows at three per CU (profiles/r03_ab.md)
+    static const int ilp_env = getenv("PF_A_ILP") ? atoi(getenv("PF_A_ILP")) : 0;
+    const int ilp = ilp_env > 0 ? ilp_env : (lay.f32 ? 3 : 2);
     unsigned long long* st = nullptr;
     if (stamp) {
         if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
@@ -1588,10 +1591,15 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // warped pixel instead of three.  Measured on MI355X (profiles/r03_ab.md): fp32 +1.8 %, int16 +-0 against the weight
     // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
     static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
-    if (wa && !wplane && !st && BH == 32 && ilp == 3) {
+    if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2)) {
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
-        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
-        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        if (lay.f32) {
+            if (ilp == 3) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+            else          hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        } else {
+            if (ilp == 3) hipLaunchKernelGGL((k_levels<false, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+            else          hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        }
         return;
     }
     if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)

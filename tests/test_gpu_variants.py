@@ -3,7 +3,7 @@ tests in a child process (the switches are read once per process):
   PF_PATCH=1         LDS-staged source / weight patch for the warp (profiles/r03_patch_stage_a.md)
   PF_WEIGHT_PLANE=1  radial weight gathered from the fp32 weight plane instead of computed
   PF_TABLE_COPY=1    tile tables staged and copied in the stream instead of travelling in the kernel arguments
-  PF_A_ILP=2         two warp rows per step
+  PF_A_ILP=2 / 3     two / three warp rows per step for both pyramid types (defaults: fp32 3, int16 2)
 Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:311-558 (renderFrame)."""
 import os
 import subprocess
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2"])
+@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3"])
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
