@@ -354,3 +354,31 @@ def test_prepare_again_resets_the_map(pf, thread):
     assert b.sync()
     assert a.grid() == b.grid()
     assert map_digest(a) == map_digest(b)
+
+
+def test_section_timers_carry_the_reference_names(pf):
+    """pi::timer's sections (PIL/src/base/time/Timer.h:43-85; MultiBandMap2DCPU.cpp:476,555,563,602,628-630,722,742) on the
+    host side of the HIP path: one feed / renderFrame / Apply per accepted keyframe, spreadMap when the grid grows,
+    updateTexture per blend batch, save once; min <= mean <= max."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(6, seed=5)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    for k, p in enumerate(poses):
+        assert g.feed(wl.noise_frame(480, 640, k), p)
+    assert g.sync()
+    assert len(g.blend_changed()[0]) > 0
+    assert g.save_to_memory() is not None
+    t = g.timers()
+    assert set(t) == {"Map2D::feed", "MultiBandMap2DCPU::renderFrame", "MultiBandMap2DCPU::Apply", "MultiBandMap2DCPU::spreadMap",
+                      "MultiBandMap2DCPU::updateTexture", "MultiBandMap2DCPU::save"}
+    assert t["Map2D::feed"]["calls"] == t["MultiBandMap2DCPU::renderFrame"]["calls"] == t["MultiBandMap2DCPU::Apply"]["calls"] == len(poses)
+    assert t["MultiBandMap2DCPU::updateTexture"]["calls"] >= 1          # (spreadMap only when a frame leaves the prepared grid)
+    assert t["MultiBandMap2DCPU::save"]["calls"] >= 1
+    for v in t.values():
+        if v["calls"]:
+            assert 0 < v["min_s"] <= v["mean_s"] <= v["max_s"] < 5.0
+    assert t["MultiBandMap2DCPU::Apply"]["mean_s"] <= t["MultiBandMap2DCPU::renderFrame"]["mean_s"] <= t["Map2D::feed"]["mean_s"]
+    g.timer_reset()
+    assert all(v["calls"] == 0 for v in g.timers().values())
