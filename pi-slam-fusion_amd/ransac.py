@@ -21,6 +21,8 @@ SIGMA = 0.15          # inlier distance, RANSAC.cpp:62
 CONFIDENCE = 0.999    # RANSAC.cpp:66
 MAX_ITERS = 10000     # RANSAC.cpp:60
 MIN_POINTS = 2000     # RANSAC.cpp:112
+REF_PI = 3.1415926535  # the constant RANSAC.cpp:25 folds the angle with (not M_PI): kept, so that the published
+                       # quaternion equals the reference's to the last bit (tests/golden/ransac_vectors.json)
 
 
 def _sub(a, b):
@@ -50,13 +52,14 @@ def plane_from_points(a, b, c):
     ln = math.sqrt(_dot(n, n))
     if ln == 0.0:
         return None
-    n = (n[0] / ln, n[1] / ln, n[2] / ln)
+    inv = 1.0 / ln                                        # Point3_::normalize multiplies by 1./norm() (Point.h:158-164)
+    n = (n[0] * inv, n[1] * inv, n[2] * inv)
     z = (0.0, 0.0, 1.0)
     axis = _cross(n, z)
-    angle = math.acos(max(-1.0, min(1.0, _dot(n, z))))
-    if angle > math.pi / 2.0:
-        angle = math.pi - angle
-        axis = (-axis[0], -axis[1], -axis[2])
+    angle = math.acos(max(-1.0, min(1.0, _dot(n, z))))    # (a unit normal's z never leaves [-1, 1] by more than rounding)
+    if angle > REF_PI / 2.0:
+        angle = REF_PI - angle
+        axis = (axis[0] * -1, axis[1] * -1, axis[2] * -1)
     s = math.sin(angle / 2.0)
     # the reference scales the UNnormalised axis (|axis| = sin(angle)) by sin(angle/2), RANSAC.cpp:46-48;
     # kept as is -- the result is a non-unit quaternion whose direction is the rotation's axis
