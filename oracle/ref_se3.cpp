@@ -6,10 +6,11 @@
 // never into git.  tests/golden/make_se3_vectors.py runs it and commits the
 // JSON it prints as tests/golden/se3_vectors.json.
 //
-// What is pinned: plane.inverse()*pose (Map2D.cpp:45, MultiBandMap2DCPU.cpp:297),
+// What is pinned: the image type codes of the boundary (GImage.h:97-101); plane.inverse()*pose (Map2D.cpp:45, MultiBandMap2DCPU.cpp:297),
 // SO3*Point3d (the quaternion sandwich) and the four-corner ground footprint
 // with the 0.4 obliqueness gate (MultiBandMap2DCPU.cpp:324-347).
 #include <GSLAM/core/SE3.h>
+#include <GSLAM/core/GImage.h>
 #include <cstdio>
 #include <cstdint>
 #include <cmath>
@@ -73,6 +74,10 @@ int main() {
         printf("\"ok\":%d,\"pts\":[%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g]}%s\n", ok ? 1 : 0,
                pts[0], pts[1], pts[2], pts[3], pts[4], pts[5], pts[6], pts[7], c + 1 < N ? "," : "");
     }
-    printf("]}\n");
+    // image type codes of the boundary (pf_image.type == cv::Mat::type() == GImage::type(), GImage.h:97-101): the
+    // reference's own GImageType<element, channels>::Type for the types Map2D::feed and the Ele pyramids use
+    printf("],\n\"gimage_types\":{\"8UC1\":%d,\"8UC3\":%d,\"8UC4\":%d,\"16SC3\":%d,\"32FC1\":%d,\"32FC3\":%d}}\n",
+           (int)GSLAM::GImageType<uint8_t, 1>::Type, (int)GSLAM::GImageType<uint8_t, 3>::Type, (int)GSLAM::GImageType<uint8_t, 4>::Type,
+           (int)GSLAM::GImageType<int16_t, 3>::Type, (int)GSLAM::GImageType<float, 1>::Type, (int)GSLAM::GImageType<float, 3>::Type);
     return 0;
 }

@@ -76,6 +76,16 @@ def test_host_geometry_matches_reference_headers(pf, orc):
     assert 0 < n_ok < len(vec["cases"])
 
 
+def test_image_type_codes_are_the_reference_headers(pf):
+    """pf_image.type is cv::Mat::type() / GImage::type(): the codes in include/pifusion.h equal the reference's own
+    GSLAM::GImageType<element, channels>::Type (GImage.h:97-101), printed by oracle/_ref/se3_ref into the golden file."""
+    types = json.load(open(os.path.join(ROOT, "tests", "golden", "se3_vectors.json")))["gimage_types"]
+    src = open(os.path.join(ROOT, "include", "pifusion.h")).read()
+    declared = {k: int(v) for k, v in re.findall(r"PF_(\d+[USF]C\d)\s*=\s*(\d+)", src)}
+    assert declared == types
+    assert (pf.PF_8UC3, pf.PF_8UC4, pf.PF_16SC3, pf.PF_32FC3) == (types["8UC3"], types["8UC4"], types["16SC3"], types["32FC3"])
+
+
 def test_perspective_transform_same_in_product_and_oracle(pf, orc):
     rng = np.random.RandomState(0)
     for _ in range(50):
