@@ -13,14 +13,17 @@ import numpy as np
 
 
 def parse_config(path):
-    """Subset of the svar grammar the dataset files use: `key = value`, `key ?= value`, comments."""
+    """Subset of the svar grammar the dataset files use: `key = value`, `key ?= value` (assign only if unset), comments
+    (GSLAM/core/Svar.h; pinned by tests/golden/svar_vectors.json, made with the reference's own parser)."""
     out = {}
     for line in open(path):
         line = line.split("//")[0].split("#")[0].strip()
-        m = re.match(r"^([\w.]+)\s*\??=\s*(.*)$", line)
+        m = re.match(r"^([\w.]+)\s*(\??=)\s*(.*)$", line)
         if not m:
             continue
-        key, val = m.group(1), m.group(2).strip()
+        key, weak, val = m.group(1), m.group(2) == "?=", m.group(3).strip()
+        if weak and key in out:
+            continue
         nums = re.findall(r"[-+]?\d*\.?\d+(?:[eE][-+]?\d+)?", val)
         out[key] = [float(x) for x in nums] if nums and re.fullmatch(r"[\[\]\s,\d.eE+-]+", val) else val
     return out
