@@ -342,8 +342,9 @@ struct LevelArgs {
     int tiles_x;
     int top_select;               // i+1 == L: select the top level from B
     int write_next;               // i+1 <  L: write GW_{i+1}
-    int nbx, nby;                 // block grid
+    int nbx, nby;                 // block grid (k_strips: strips x segments)
     int ablate;                   // diagnostics only (PF_ABLATE): bit0 skip A math, bit1 skip H/B, bit2 skip U/D
+    int seg;                      // k_strips: rows of a strip segment
 };
 
 // 1/d exactly as the compiler's IEEE fp64 division computes it when no operand scaling is needed
@@ -1411,6 +1412,8 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
                                                        J.table, bb, st, tab0);
 }
 
+#include "strips.inc"
+
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
 static int plain_homography(const WarpArgs& wa)
 {
@@ -1524,8 +1527,61 @@ static unsigned long long* g_stamp_buf = nullptr;
 static int g_stamp_blocks = 0;
 constexpr int kStampBlocks = 1 << 16;
 
+// The wave-specialised rolling-strip form of the pipelined launch (strips.inc).  Returns false when this launch has to take
+// the block form (diagnostic builds, the gathered weight plane).
+static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
+{
+    static const int on = getenv("PF_STRIPS") ? atoi(getenv("PF_STRIPS")) : 0;      // default off until it beats the block form (profiles/r04_strips.md)
+    static const int sablate = getenv("PF_SABLATE") ? atoi(getenv("PF_SABLATE")) : 0;      // timing only: 1 no warp, 2 no pyrDown, 4 no select, 8 no weight prefetch
+    static const bool other = getenv("PF_STAMP") || getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") ||
+                              getenv("PF_INTERLEAVE_JOBS") || getenv("PF_UPPER_FIRST") || getenv("PF_A_ILP");
+    if (!on || other) return false;
+    constexpr int R = 4;
+    static const int seg_env = getenv("PF_STRIP_SEG") ? atoi(getenv("PF_STRIP_SEG")) : 0;
+    const int seg = seg_env >= R ? (seg_env / R) * R : 64;
+    LevelBatch batch{};
+    int first_blocks = 0, upper_blocks = 0;
+    for (int k = 0; k < njobs; k++) {
+        const LevelLaunch& q = jobs[k];
+        LevelJob& J = batch.job[batch.njobs];
+        J.g.level = q.level; J.g.rows = q.rows; J.g.cols = q.cols; J.g.cx0 = q.cx0; J.g.cy0 = q.cy0; J.g.cx1 = q.cx1; J.g.cy1 = q.cy1;
+        J.g.tiles_x = q.tiles_x; J.g.top_select = q.top_select; J.g.write_next = q.write_next; J.g.ablate = sablate;
+        J.g.seg = seg;
+        J.g.nbx = (q.cx1 - q.cx0 + strips::KW - 1) / strips::KW; J.g.nby = (q.cy1 - q.cy0 + seg - 1) / seg;
+        if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
+        if ((q.cx0 | q.cy0 | q.cy1) & 1) return false;          // strips start on even columns / rows (they always do: regions are tile- or 2x-aligned)
+        J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
+        J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
+        J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
+        for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        if (batch.njobs == 0 && q.table_args && q.table_n > 0 && q.table_n <= kArgTable) {
+            batch.tab0_n = q.table_n;
+            for (int i = 0; i < q.table_n; i++) batch.tab0[i] = q.table_args[i];
+        }
+        const int padded = (J.g.nbx * J.g.nby + 7) & ~7;
+        if (batch.njobs == 0) { J.first = 0; first_blocks = padded; }
+        else { J.first = upper_blocks; upper_blocks += padded; }
+        batch.njobs++;
+    }
+    if (!batch.njobs) return true;
+    const int nblocks = first_blocks + upper_blocks;
+    batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8; batch.sequential = 1;
+    FusedWarp w{};
+    if (wa) {
+        for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
+        w.total = frame_bytes(wa->srows, wa->scols, wa->sstep, wa->src_cn); w.wmap = wa->wmap;
+        w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
+        w.plain = plain_homography(*wa);
+        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
+    }
+    if (lay.f32) hipLaunchKernelGGL((k_strips<true, R, 4, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
+    else         hipLaunchKernelGGL((k_strips<false, R, 4, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
+    return true;
+}
+
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
 {
+    if (level_block_rows(lay.f32 != 0) == 32 && launch_strips(s, lay, jobs, njobs, wa, src)) return;
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const int BH = level_block_rows(lay.f32 != 0);
     LevelBatch batch{};

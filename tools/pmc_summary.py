@@ -27,8 +27,13 @@ SHORT = [("k_warp", "warp"), ("k_pyrdown<float, float, 1>", "pyrdown_w"), ("k_py
          ("k_single", "single_band")]
 
 
+def pipelined(name):
+    """the one-launch-per-keyframe kernels: the block form (k_levels) and the rolling-strip form (k_strips, r04)"""
+    return "k_levels<" in name or "k_strips<" in name
+
+
 def short(name):
-    if "k_levels<" in name:          # pipelined launch: level 0 of a frame + upper levels of earlier frames
+    if pipelined(name):          # pipelined launch: level 0 of a frame + upper levels of earlier frames
         return "level0_fused"
     m = re.search(r"k_level3?<(\w+), (\w+)", name)
     if m:
@@ -61,7 +66,7 @@ def full_launches(d):
     """k_levels only: mean duration of the full-size launches (one per keyframe) from the per-dispatch trace,
     i.e. without the short flush launches before a sync -- the launches bench.py puts its events around"""
     try:
-        rows = [r for r in csv.DictReader(open(find(d, "*_kernel_trace.csv"))) if "k_levels<" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(find(d, "*_kernel_trace.csv"))) if pipelined(r["Kernel_Name"])]
     except SystemExit:
         return
     if not rows:
@@ -70,7 +75,7 @@ def full_launches(d):
     full = max(size(r) for r in rows)
     dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if size(r) * 2 > full]
     print()
-    print("`k_levels` full-size launches only (%d of %d dispatches): avg %.2f us, min %.2f us, max %.2f us" %
+    print("pipelined level kernel, full-size launches only (%d of %d dispatches): avg %.2f us, min %.2f us, max %.2f us" %
           (len(dur), len(rows), sum(dur) / len(dur), min(dur), max(dur)))
 
 
@@ -78,8 +83,8 @@ def counter_rows(d):
     """rows of a --pmc pass; the pipelined k_levels launches are kept only at full size (a keyframe's launch), not
     the short flush launches before a sync that carry upper levels only -- the same launches bench.py times"""
     rows = [r for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))) if short(r["Kernel_Name"])]
-    full = max([int(r["Grid_Size"]) for r in rows if "k_levels<" in r["Kernel_Name"]] or [0])
-    return [r for r in rows if "k_levels<" not in r["Kernel_Name"] or int(r["Grid_Size"]) * 2 > full]
+    full = max([int(r["Grid_Size"]) for r in rows if pipelined(r["Kernel_Name"])] or [0])
+    return [r for r in rows if not pipelined(r["Kernel_Name"]) or int(r["Grid_Size"]) * 2 > full]
 
 
 def counter_means(d, counter):
