@@ -1533,7 +1533,8 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
 {
     static const int on = getenv("PF_STRIPS") ? atoi(getenv("PF_STRIPS")) : 0;      // default off until it beats the block form (profiles/r04_strips.md)
     static const int sablate = getenv("PF_SABLATE") ? atoi(getenv("PF_SABLATE")) : 0;      // timing only: 1 no warp, 2 no pyrDown, 4 no select, 8 no weight prefetch
-    static const bool other = getenv("PF_STAMP") || getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") ||
+    static const bool stamp = getenv("PF_STAMP") != nullptr;
+    static const bool other = getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") ||
                               getenv("PF_INTERLEAVE_JOBS") || getenv("PF_UPPER_FIRST") || getenv("PF_A_ILP");
     if (!on || other) return false;
     constexpr int R = 4;
@@ -1574,8 +1575,20 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
         w.plain = plain_homography(*wa);
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
     }
-    if (lay.f32) hipLaunchKernelGGL((k_strips<true, R, 4, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
-    else         hipLaunchKernelGGL((k_strips<false, R, 4, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src);
+    constexpr int P = PF_S_P;
+    if (stamp) {
+        // diagnostic build (tools/strip_roles.py): 32 u64 per workgroup -- per wave {cycles waiting at the period barriers, lifetime}, [30] job, [31] periods
+        if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, (size_t)kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
+        if (g_stamp_buf && nblocks * 4 <= kStampBlocks) {
+            (void)hipMemsetAsync(g_stamp_buf, 0, (size_t)kStampBlocks * 64, s);
+            g_stamp_blocks = nblocks * 4;
+            if (lay.f32) hipLaunchKernelGGL((k_strips<true, R, P, true, true>), dim3(nblocks), dim3((P + 4) * 64), 0, s, batch, w, src, g_stamp_buf);
+            else         hipLaunchKernelGGL((k_strips<false, R, P, true, true>), dim3(nblocks), dim3((P + 4) * 64), 0, s, batch, w, src, g_stamp_buf);
+            return true;
+        }
+    }
+    if (lay.f32) hipLaunchKernelGGL((k_strips<true, R, P, true>), dim3(nblocks), dim3((P + 4) * 64), 0, s, batch, w, src, (unsigned long long*)nullptr);
+    else         hipLaunchKernelGGL((k_strips<false, R, P, true>), dim3(nblocks), dim3((P + 4) * 64), 0, s, batch, w, src, (unsigned long long*)nullptr);
     return true;
 }
 
