@@ -131,6 +131,21 @@ int     pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr256);
 /* batch form of the draw() loop (.cpp:705-742): blend every tile whose
  * Ischanged flag is set, clear the flags; xy/bgr sized by cap tiles.       */
 int     pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap);
+/* The text draw() hands to scommand.Call("MapWidget", ...) for a refreshed tile when Fuse2Google is set
+ * (MultiBandMap2DCPU.cpp:744-757): "Map2DUpdate LastTexMat <lng lat 0 of the tile's top-left corner> <... bottom-right>".
+ * Byte for byte the reference's string: tile corners rounded to float first (.cpp:709-712), plane * corner, then
+ * pi::calcLngLatFromDistance around GPS.Origin (PIL/src/hardware/Gps/utils_GPS.cpp:133-160), every field through
+ * std::to_string -- six decimals; the call site's setprecision(9) never reaches a number (GSLAM/core/Point.h:166-170).
+ * pf_format_map_update: the pure function (grid minimum, tile edge in metres, dense tile index x, y as the draw() loop counts).
+ * pf_map_update_command: the same for tile (ix, iy) of a prepared map (stable tile coordinates), with the reference's gate
+ * `updated && !inborder`: 0 when the tile holds no pyramid yet, or lies on the rim of the dense grid while
+ * HighQualityShow is on (one of its 3x3 neighbours falls outside, .cpp:730-735).  `Fuse2Google` itself is the caller's flag.
+ * Both return the length written (without the terminating 0), 0 when nothing is to be sent or cap is too small. */
+int     pf_format_map_update(const double plane[7], const double gps_origin[3], double min_x, double min_y, double ele_size,
+                             int x, int y, char* out, int cap);
+int     pf_map_update_command(pf_map* m, int ix, int iy, const double gps_origin[3], char* out, int cap);
+/* pi::calcLngLatFromDistance (utils_GPS.cpp:133-160) alone */
+void    pf_lnglat_from_distance(double lng1, double lat1, double dx, double dy, double* lng2, double* lat2);
 /* unused-by-the-reference helpers kept for API completeness (.cpp:57-75)   */
 int     pf_normalize_using_weight_map(const float* weight, float* src3, size_t npix);
 int     pf_mul_weight_map(const float* weight, float* src3, size_t npix);

@@ -119,16 +119,25 @@ public:
         const pf_image v = pifusion::view(img);
         return pf_feed(h_, &v, p) != 0;
     }
-    // draw(): refresh every tile whose Ischanged flag is set and pass (ix, iy, BGR8 256x256) on
-    void draw(const std::function<void(int, int, const unsigned char*)>& sink = nullptr)
+    // draw(): refresh every tile whose Ischanged flag is set and pass (ix, iy, BGR8 256x256) on.
+    // With fuseGoogle() set, `announce` receives what the reference hands to scommand.Call("MapWidget", ...) for every refreshed
+    // tile that is not on the rim of the grid (MultiBandMap2DCPU.cpp:744-757): "Map2DUpdate LastTexMat <gpsTL> <gpsBR>".
+    void draw(const std::function<void(int, int, const unsigned char*)>& sink = nullptr,
+              const std::function<void(const std::string&)>& announce = nullptr)
     {
         const int cap = pf_tile_count(h_);
         if (cap <= 0) return;
         std::vector<int> xy(2 * (size_t)cap);
         std::vector<unsigned char> px((size_t)cap * ELE_PIXELS * ELE_PIXELS * 3);
         const int n = pf_blend_changed(h_, xy.data(), px.data(), cap);
-        if (sink) for (int i = 0; i < n; i++) sink(xy[2 * i], xy[2 * i + 1], &px[(size_t)i * ELE_PIXELS * ELE_PIXELS * 3]);
+        for (int i = 0; i < n; i++) {
+            if (sink) sink(xy[2 * i], xy[2 * i + 1], &px[(size_t)i * ELE_PIXELS * ELE_PIXELS * 3]);
+            char cmd[256];
+            if (fuse2google_ && announce && pf_map_update_command(h_, xy[2 * i], xy[2 * i + 1], gps_origin_, cmd, (int)sizeof cmd) > 0) announce(cmd);
+        }
     }
+    // svar "Fuse2Google" and "GPS.Origin" (longitude latitude altitude) of the reference (.cpp:196, :744)
+    void fuseGoogle(bool on, double lng = 0, double lat = 0, double alt = 0) { fuse2google_ = on; gps_origin_[0] = lng; gps_origin_[1] = lat; gps_origin_[2] = alt; }
     bool save(const std::string& filename) { return pf_save(h_, filename.c_str()) != 0; }
     unsigned queueSize() { return pf_queue_size(h_); }
     bool sync() { return pf_sync(h_) != 0; }
@@ -151,6 +160,8 @@ public:
 private:
     explicit Map2D(pf_map* h) : h_(h) {}
     pf_map* h_;
+    bool fuse2google_ = false;
+    double gps_origin_[3] = { 0, 0, 0 };
 };
 
 #endif  // PIFUSION_MAP2D_H

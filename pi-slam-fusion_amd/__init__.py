@@ -94,6 +94,9 @@ def lib():
     L.pf_blend_tile_raw.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_tile.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_changed.argtypes = [vp, ip, vp, C.c_int]
+    L.pf_format_map_update.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.pf_map_update_command.argtypes = [vp, C.c_int, C.c_int, dp, C.c_char_p, C.c_int]
+    L.pf_lnglat_from_distance.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]; L.pf_lnglat_from_distance.restype = None
     L.pf_normalize_using_weight_map.argtypes = [vp, vp, C.c_size_t]
     L.pf_mul_weight_map.argtypes = [vp, vp, C.c_size_t]
     L.pf_tile_owner.argtypes = [C.POINTER(Options), C.c_int, C.c_int]
@@ -145,6 +148,21 @@ def default_options(**kw):
 
 def se3_inverse(a):
     a, pa = _pose(a); o = np.zeros(7); lib().pf_se3_inverse(pa, o.ctypes.data_as(C.POINTER(C.c_double))); return o
+
+
+def format_map_update(plane, gps_origin, min_x, min_y, ele_size, x, y):
+    """pf_format_map_update: the reference's Map2DUpdate text for dense tile index (x, y) (C implementation)."""
+    _, pp = _pose(plane)
+    buf = C.create_string_buffer(256)
+    g = (C.c_double * 3)(*[float(v) for v in gps_origin])
+    n = lib().pf_format_map_update(pp, g, float(min_x), float(min_y), float(ele_size), int(x), int(y), buf, 256)
+    return buf.value.decode() if n > 0 else None
+
+
+def lnglat_from_distance(lng1, lat1, dx, dy):
+    a, b = C.c_double(), C.c_double()
+    lib().pf_lnglat_from_distance(float(lng1), float(lat1), float(dx), float(dy), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def se3_mul(a, b):
@@ -309,6 +327,14 @@ class Map2D:
     def blend_tile(self, ix, iy):
         out = np.empty((ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
         return out if lib().pf_blend_tile(self._h, ix, iy, out.ctypes.data) else None
+
+    def map_update_command(self, ix, iy, gps_origin):
+        """draw()'s "Map2DUpdate LastTexMat ..." text for tile (ix, iy), or None under the reference's gate
+        `updated && !inborder` (MultiBandMap2DCPU.cpp:744); Fuse2Google is the caller's flag."""
+        buf = C.create_string_buffer(256)
+        g = (C.c_double * 3)(*[float(v) for v in gps_origin])
+        n = lib().pf_map_update_command(self._h, ix, iy, g, buf, 256)
+        return buf.value.decode() if n > 0 else None
 
     def blend_changed(self, cap=4096):
         xy = (C.c_int * (2 * cap))()

@@ -1,6 +1,8 @@
 // c_api.cpp -- extern "C" surface of libpifusion.so (include/pifusion.h).
 #include "dist.hpp"
 #include <cstdlib>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <new>
 
@@ -98,6 +100,49 @@ int pf_mul_weight_map(const float* weight, float* src3, size_t npix)
 
 static pf::Pose to_pose(const double a[7]) { return pf::pose_from7(a); }
 static void from_pose(const pf::Pose& p, double o[7]) { std::memcpy(o, p.t, 24); std::memcpy(o + 3, p.q, 32); }
+// pi::calcLngLatFromDistance, PIL/src/hardware/Gps/utils_GPS.cpp:133-160 (same operations in the same order; DEG2RAD is the
+// reference's truncated constant)
+void pf_lnglat_from_distance(double lng1, double lat1, double dx, double dy, double* lng2, double* lat2)
+{
+    const double kEarthRadius = 6378137.0, kDeg2Rad = 0.017453292519943;
+    const double a = kEarthRadius, f = 1.0 / 298.257223563, e_2 = 2 * f - f * f;
+    const double phi_rad = lat1 * kDeg2Rad;
+    const double sp = std::sin(phi_rad);
+    const double lng_unit = kDeg2Rad * a * std::cos(phi_rad) / std::sqrt(1 - e_2 * (sp * sp));
+    const double lat_unit = kDeg2Rad * a * (1 - e_2) / std::pow(1 - e_2 * (sp * sp), 1.5);
+    if (lng2) *lng2 = dx / lng_unit + lng1;
+    if (lat2) *lat2 = dy / lat_unit + lat1;
+}
+
+// MultiBandMap2DCPU.cpp:709-712 + :747-755
+int pf_format_map_update(const double plane[7], const double gps_origin[3], double min_x, double min_y, double ele_size,
+                         int x, int y, char* out, int cap)
+{
+    if (!plane || !gps_origin || !out || cap <= 0) return 0;
+    const float x0 = (float)(min_x + x * ele_size), y0 = (float)(min_y + y * ele_size);
+    const float x1 = (float)(x0 + ele_size), y1 = (float)(y0 + ele_size);
+    const pf::Pose pl = to_pose(plane);
+    double gps[2][2];
+    const float cx[2] = { x0, x1 }, cy[2] = { y0, y1 };
+    for (int k = 0; k < 2; k++) {
+        const double p[3] = { (double)cx[k], (double)cy[k], 0.0 };
+        double r[3];
+        pf::rotate(pl.q, p, r);                                   // SE3 * Point3d = translation + rotation * p (SE3.h:99-101)
+        pf_lnglat_from_distance(gps_origin[0], gps_origin[1], pl.t[0] + r[0], pl.t[1] + r[1], &gps[k][0], &gps[k][1]);
+    }
+    // std::to_string(double) is "%f"
+    const int n = std::snprintf(out, (size_t)cap, "Map2DUpdate LastTexMat %f %f %f %f %f %f", gps[0][0], gps[0][1], 0.0, gps[1][0], gps[1][1], 0.0);
+    return (n > 0 && n < cap) ? n : 0;
+}
+
+int pf_map_update_command(pf_map* m, int ix, int iy, const double gps_origin[3], char* out, int cap)
+{
+    if (!m || !gps_origin || !out) return 0;
+    double plane[7], mn[2], ele; int x, y;
+    if (!m->impl.map_update_inputs(ix, iy, plane, mn, &ele, &x, &y)) return 0;
+    return pf_format_map_update(plane, gps_origin, mn[0], mn[1], ele, x, y, out, cap);
+}
+
 void pf_se3_inverse(const double a[7], double out[7]) { from_pose(pf::inverse(to_pose(a)), out); }
 void pf_se3_mul(const double a[7], const double b[7], double out[7]) { from_pose(pf::mul(to_pose(a), to_pose(b)), out); }
 void pf_so3_rotate(const double q[4], const double p[3], double out[3]) { pf::rotate(q, p, out); }

@@ -1099,6 +1099,20 @@ bool FusionMap::grid(int dims[4], double geo[6])
     return true;
 }
 
+bool FusionMap::map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!valid_) return false;
+    Tile* t = store_.find(ix, iy);
+    if (!t || t->fresh) return false;                            // .cpp:717-718: no pyramid yet
+    const int dx = ix - off_x_, dy = iy - off_y_;                // dense index of the draw() loop
+    if (dx < 0 || dy < 0 || dx >= w_ || dy >= h_) return false;
+    if (opt_.high_quality_show && !single_band_ && (dx == 0 || dy == 0 || dx == w_ - 1 || dy == h_ - 1)) return false;   // inborder
+    std::memcpy(plane7, plane_.t, 24); std::memcpy(plane7 + 3, plane_.q, 32);
+    mn[0] = min_[0]; mn[1] = min_[1]; *ele = ele_size_; *x = dx; *y = dy;
+    return true;
+}
+
 int FusionMap::tile_count()
 {
     std::lock_guard<std::mutex> l(mu_);

@@ -113,6 +113,9 @@ public:
     hipStream_t stream() const { return stream_; }
     int  device() const { return device_; }
     bool use_device() { return set_device(); }
+    // draw()'s Fuse2Google gate and operands for tile (ix, iy) (MultiBandMap2DCPU.cpp:709-712, :730-735, :744): false when the tile
+    // has no pyramid, or lies on the rim of the dense grid while HighQualityShow is on
+    bool map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y);
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
     int  num_levels() const { return band_num_ + 1; }

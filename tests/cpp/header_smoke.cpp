@@ -50,6 +50,15 @@ int main()
     map->draw([&](int, int, const unsigned char* bgr) { n += bgr[0] >= 0; });
     std::printf("tiles refreshed: %d\n", n);
     if (n <= 0) return 6;
+    // the overlay message of draw() (MultiBandMap2DCPU.cpp:744-757): every refreshed tile off the rim of the grid is announced
+    {
+        for (auto& f : frames) if (!map->feed(f.first, f.second)) return 12;
+        int told = 0, bad = 0;
+        map->fuseGoogle(true, 108.888931, 34.257287, 400.0);
+        map->draw(nullptr, [&](const std::string& s) { told++; bad += s.compare(0, 23, "Map2DUpdate LastTexMat ") != 0; std::printf("%s\n", s.c_str()); });
+        std::printf("tiles announced: %d\n", told);
+        if (bad) return 13;
+    }
 
     // A ROI of a wider buffer (cv::Mat::step > cols * channels) through the C++ face: the row pitch must travel.
     // Same pixels packed and padded -> the same tiles.

@@ -120,21 +120,67 @@ def test_live_wire_cfg4(pf, orc, tmp_path):
     assert np.array_equal(m.save_to_memory()[0], o.save()[0])
 
 
-def test_overlay_message_format(pf):
-    """Row f4: Map2DUpdate message (MultiBandMap2DCPU.cpp:744-757), GPS maths of utils_GPS.cpp:133-160."""
+def _gps_vectors():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gps_vectors.json")))
+
+
+def test_overlay_message_equals_reference(pf):
+    """Row f4: the Map2DUpdate message (MultiBandMap2DCPU.cpp:744-757) against strings printed by the reference's own
+    operator<<(Point3d) / SE3 * Point3d / calcLngLatFromDistance (oracle/ref_gps.cpp -> tests/golden/gps_vectors.json):
+    Python (overlay.py) and the C ABI (pf_format_map_update) reproduce every message byte for byte, and the GPS maths bit for bit."""
     ov = importlib.import_module("pi_slam_fusion_amd.overlay")
-    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 0.0, 0.0)
-    assert (lng, lat) == (108.888931, 34.257287)
-    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 92.0, 0.0)      # ~92 m per 0.001 deg of longitude at 34 N
-    assert abs(lng - 108.889931) < 2e-5 and lat == 34.257287
-    lng, lat = ov.lnglat_from_distance(108.888931, 34.257287, 0.0, 110.9)     # ~110.9 m per 0.001 deg of latitude
-    assert abs(lat - 34.258287) < 2e-5
+    g = _gps_vectors()
+    assert len(g["lnglat"]) >= 16 and len(g["messages"]) >= 16
+    for v in g["lnglat"]:
+        assert ov.lnglat_from_distance(v["lng1"], v["lat1"], v["dx"], v["dy"]) == (v["lng2"], v["lat2"])
+        assert pf.lnglat_from_distance(v["lng1"], v["lat1"], v["dx"], v["dy"]) == (v["lng2"], v["lat2"])
+    for v in g["messages"]:
+        want = v["cmd"]
+        assert want.startswith("Map2DUpdate LastTexMat ") and len(want.split()) == 8
+        assert all(len(f.split(".")[1]) == 6 for f in want.split()[2:])          # std::to_string: six decimals, not the call site's nine
+        assert ov.format_map_update(pf, v["plane"], v["origin"], v["min"][0], v["min"][1], v["ele"], v["x"], v["y"]) == want
+        assert pf.format_map_update(v["plane"], v["origin"], v["min"][0], v["min"][1], v["ele"], v["x"], v["y"]) == want
+
+
+def test_overlay_gate(pf):
+    """`updated && !inborder && Fuse2Google` (.cpp:744): rim tiles of the dense grid are never announced while HighQualityShow is on."""
+    ov = importlib.import_module("pi_slam_fusion_amd.overlay")
 
     class FakeMap:
         def grid(self):
             return [10, 8, -2, -1], [-100.0, -50.0, 412.0, 359.6, 51.2, 0.2]
-    s = ov.tile_overlay_command(pf, FakeMap(), [0, 0, 0, 0, 0, 0, 1], [108.888931, 34.257287, 400.0], 0, 1)
-    parts = s.split()
-    assert parts[:2] == ["Map2DUpdate", "LastTexMat"] and len(parts) == 8 and parts[4] == "0.000000000"
-    x0 = -100.0 + 2 * 51.2
-    assert abs(float(parts[2]) - ov.lnglat_from_distance(108.888931, 34.257287, x0, 0)[0]) < 1e-9
+    plane, org = [0, 0, 0, 0, 0, 0, 1], [108.888931, 34.257287, 400.0]
+    assert ov.tile_overlay_command(pf, FakeMap(), plane, org, -2, 3) is None              # x == 0: a neighbour outside the grid
+    assert ov.tile_overlay_command(pf, FakeMap(), plane, org, 7, 6) is None               # x == w-1, y == h-1
+    assert ov.tile_overlay_command(pf, FakeMap(), plane, org, 3, 3, fuse2google=False) is None
+    s = ov.tile_overlay_command(pf, FakeMap(), plane, org, 0, 1)
+    assert s == ov.format_map_update(pf, plane, org, -100.0, -50.0, 51.2, 2, 2)
+    assert ov.tile_overlay_command(pf, FakeMap(), plane, org, -2, 3, high_quality_show=False) is not None
+
+
+@pytest.mark.gpu
+def test_overlay_from_map(pf):
+    """pf_map_update_command on a real map: interior tiles with pyramids give the reference's text, rim tiles and
+    tiles without pyramids give nothing."""
+    ov = importlib.import_module("pi_slam_fusion_amd.overlay")
+    wl = workloads()
+    cam, poses = wl.cfg1(6, step=40.0)
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        assert m.feed(wl.noise_frame(480, 640, k), p)
+    m.sync()
+    org = [108.888931, 34.257287, 400.0]
+    dims, geo = m.grid()
+    told = 0
+    for (ix, iy) in m.tiles():
+        x, y = ix - dims[2], iy - dims[3]
+        rim = x == 0 or y == 0 or x == dims[0] - 1 or y == dims[1] - 1
+        got = m.map_update_command(ix, iy, org)
+        want = None if rim else ov.format_map_update(pf, wl.IDENTITY_PLANE, org, geo[0], geo[1], geo[4], x, y)
+        assert got == want, (ix, iy, got, want)
+        told += got is not None
+    assert told > 0
+    assert m.map_update_command(10 ** 6, 10 ** 6, org) is None
+    m.close()
