@@ -235,7 +235,11 @@ int      pf_dist_plan_blend(int nranks, int me, const int* counts, const int* li
 int      pf_dist_info(pf_dist* d, int* rank, int* nranks, const char** transport);
 /* end-to-end check of every data exchange of the following pf_dist_* calls (default: on iff PF_DIST_VERIFY is set): each
  * rank hashes (FNV-1a) what it sent to and what it received from each peer, the hashes travel as a control message and
- * must agree; a mismatch fails the call and pf_last_error names the pair.  Costs a device-to-host copy of the payload. */
+ * must agree; a mismatch fails the call ON EVERY RANK ALIKE (the verdict is agreed on after the hash exchange, so the sender of
+ * wrong bytes returns -1 as well and no rank is left waiting in the next collective) and pf_last_error names the pair on the
+ * receiving rank.  One rank asking is enough: the wish travels with the status word the ranks agree on before every data
+ * exchange, so ranks started with different PF_DIST_VERIFY settings still run the same sequence of collectives.
+ * Costs a device-to-host copy of the payload. */
 int      pf_dist_set_verify(pf_dist* d, int on);
 
 /* --- measurement -------------------------------------------------------- */

@@ -240,8 +240,12 @@ bool DistMap::gather_lists(std::vector<std::vector<FusionMap::TileRec>>& all, st
 bool DistMap::agree(bool ok_here)
 {
     const int n = t_->nranks, me = t_->rank;
+    verify_now_ = verify_;
     if (n == 1) return ok_here;
-    int mine = ok_here ? 1 : 0;
+    // bit 0: this rank's side went well; bit 1: this rank wants the next data exchange hashed (PF_DIST_VERIFY / pf_dist_set_verify).
+    // The verify wish travels with the status so that ranks started with different settings still run the SAME sequence of
+    // collectives: if anyone asks, everyone hashes.
+    int mine = (ok_here ? 1 : 0) | (verify_ ? 2 : 0);
     std::vector<int> theirs(n, 1);
     std::vector<const void*> s(n, &mine); std::vector<void*> r(n, nullptr);
     std::vector<size_t> sb(n, sizeof(int)), rb(n, sizeof(int));
@@ -249,7 +253,11 @@ bool DistMap::agree(bool ok_here)
     sb[me] = rb[me] = 0;
     if (!t_->exchange_host(s, sb, r, rb, m_->stream())) return false;
     bool all = ok_here;
-    for (int p = 0; p < n; p++) if (p != me && !theirs[p]) { all = false; set_error("dist: rank " + std::to_string(p) + " reported a failure before the exchange"); }
+    for (int p = 0; p < n; p++) {
+        if (p == me) continue;
+        if (!(theirs[p] & 1)) { all = false; set_error("dist: rank " + std::to_string(p) + " reported a failure before the exchange"); }
+        if (theirs[p] & 2) verify_now_ = true;
+    }
     return all;
 }
 
@@ -266,35 +274,47 @@ static uint64_t fnv1a(const unsigned char* p, size_t n)
 bool DistMap::exchange_checked(const std::vector<const void*>& send, const std::vector<size_t>& sb, const std::vector<void*>& recv,
                                const std::vector<size_t>& rb, const char* what)
 {
-    if (!t_->exchange_dev(send, sb, recv, rb, m_->stream())) return false;
-    if (!verify_) return true;
+    // verify_now_ was agreed on by the agree() that precedes every data exchange: all ranks take the same branch here
+    if (!verify_now_) return t_->exchange_dev(send, sb, recv, rb, m_->stream());
+    // Verified form: whatever goes wrong on THIS rank (the exchange itself, a copy, a hash that does not match) becomes a flag,
+    // never an early return -- the hash exchange and the closing agree() below are collectives, and a rank that left early
+    // would leave its peers waiting in them.  Every rank returns the same verdict.
+    bool ok = t_->exchange_dev(send, sb, recv, rb, m_->stream());
     const int n = t_->nranks, me = t_->rank;
     struct Sum { uint64_t hash; uint64_t bytes; };
     std::vector<Sum> sent(n), got(n), claimed(n);
     std::vector<unsigned char> tmp;
+    auto hash_of = [&](const void* dev, size_t bytes, uint64_t& h) {
+        tmp.resize(bytes);
+        if (hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { set_error(std::string("dist verify (") + what + "): device-to-host copy failed"); ok = false; return; }
+        h = fnv1a(tmp.data(), bytes);
+    };
     for (int p = 0; p < n; p++) {
-        sent[p] = { 0, sb[p] }; got[p] = { 0, rb[p] };
+        sent[p] = { 0, sb[p] }; got[p] = { 0, rb[p] }; claimed[p] = { 0, 0 };
         if (p == me) continue;
-        if (sb[p]) { tmp.resize(sb[p]); HIP_OK(hipMemcpy(tmp.data(), send[p], sb[p], hipMemcpyDeviceToHost)); sent[p].hash = fnv1a(tmp.data(), sb[p]); }
-        if (rb[p]) { tmp.resize(rb[p]); HIP_OK(hipMemcpy(tmp.data(), recv[p], rb[p], hipMemcpyDeviceToHost)); got[p].hash = fnv1a(tmp.data(), rb[p]); }
+        if (sb[p]) hash_of(send[p], sb[p], sent[p].hash);
+        if (rb[p]) hash_of(recv[p], rb[p], got[p].hash);
     }
     std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);
     std::vector<size_t> hs(n, sizeof(Sum)), hr(n, sizeof(Sum));
     for (int p = 0; p < n; p++) { s[p] = &sent[p]; r[p] = &claimed[p]; }
     hs[me] = hr[me] = 0;
-    if (!t_->exchange_host(s, hs, r, hr, m_->stream())) return false;
-    bool ok = true;
-    for (int p = 0; p < n; p++) {
-        if (p == me) continue;
-        if (claimed[p].bytes != got[p].bytes || (got[p].bytes && claimed[p].hash != got[p].hash)) {
-            char msg[256];
-            std::snprintf(msg, sizeof msg, "dist verify (%s): rank %d sent %llu bytes (fnv %016llx), rank %d received %llu bytes (fnv %016llx)",
-                          what, p, (unsigned long long)claimed[p].bytes, (unsigned long long)claimed[p].hash, me,
-                          (unsigned long long)got[p].bytes, (unsigned long long)got[p].hash);
-            set_error(msg);
-            ok = false;
+    if (!t_->exchange_host(s, hs, r, hr, m_->stream())) ok = false;
+    else
+        for (int p = 0; p < n; p++) {
+            if (p == me) continue;
+            if (claimed[p].bytes != got[p].bytes || (got[p].bytes && claimed[p].hash != got[p].hash)) {
+                char msg[256];
+                std::snprintf(msg, sizeof msg, "dist verify (%s): rank %d sent %llu bytes (fnv %016llx), rank %d received %llu bytes (fnv %016llx)",
+                              what, p, (unsigned long long)claimed[p].bytes, (unsigned long long)claimed[p].hash, me,
+                              (unsigned long long)got[p].bytes, (unsigned long long)got[p].hash);
+                set_error(msg);
+                ok = false;
+            }
         }
-    }
+    const bool keep = verify_now_;
+    ok = agree(ok);                                           // the sender of wrong bytes learns of it too
+    verify_now_ = keep;
     stats_.verified += ok ? 1 : 0;
     return ok;
 }

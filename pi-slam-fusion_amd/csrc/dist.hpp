@@ -51,6 +51,7 @@ private:
     DevBuf send_, recv_;
     pf_dist_stats stats_{};
     bool verify_ = false;                       // PF_DIST_VERIFY=1 or pf_dist_set_verify: hash every data exchange on both ends
+    bool verify_now_ = false;                   // what the ranks agreed on for the next data exchange (any rank asking is enough)
 };
 
 }  // namespace pf

@@ -1412,6 +1412,11 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
                                                        J.table, bb, st, tab0);
 }
 
+// radial_weight() forms dis = fma(dx, dx, dy * dy): one rounding, equal to the reference's RN(RN(dy^2) + RN(dx^2)) only while
+// both squares are exact, i.e. |dx|, |dy| < 2^12.  Frames with a side of 8192 px or more (half extent >= 4096) gather the
+// weight from the plane instead (the reference's own weightImage, built by launch_weight32).
+static bool radial_weight_exact(const WarpArgs& wa) { return wa.srows < 8192 && wa.scols < 8192; }
+
 #include "strips.inc"
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
@@ -1537,6 +1542,7 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
     static const bool other = getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") ||
                               getenv("PF_INTERLEAVE_JOBS") || getenv("PF_UPPER_FIRST") || getenv("PF_A_ILP");
     if (!on || other) return false;
+    if (wa && !radial_weight_exact(*wa)) return false;
     constexpr int R = 4;
     static const int seg_env = getenv("PF_STRIP_SEG") ? atoi(getenv("PF_STRIP_SEG")) : 0;
     const int seg = seg_env >= R ? (seg_env / R) * R : 64;
@@ -1660,7 +1666,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // warped pixel instead of three.  Measured on MI355X (profiles/r03_ab.md): fp32 +1.8 %, int16 +-0 against the weight
     // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
     static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
-    if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2)) {
+    if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2) && radial_weight_exact(*wa)) {
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
         if (lay.f32) {
             if (ilp == 3) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);

@@ -11,14 +11,15 @@ from helpers import compare_maps, map_digest, workloads
 pytestmark = pytest.mark.gpu
 
 
-def test_cfg2_eight_way_sharding_at_full_frame_size(pf, orc):
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_cfg2_eight_way_sharding_at_full_frame_size(pf, orc, force_float):
     wl = workloads()
     cam = [4000, 3000, 3000, 3000, 2000, 1500]
     poses = wl.serpentine(cam, 100.0, 4, per_row=2)                     # 2 x 2 keyframes: forward and side overlap
     frames = [wl.noise_frame(3000, 4000, 40 + k) for k in range(2)]
-    o = orc.OracleMap()
-    ref = pf.Map2D.create(pf.TypeMultiBandCPU, False)
-    shards = [pf.Map2D.create(pf.TypeMultiBandCPU, False, shard_rank=r, shard_count=8, shard_block=2) for r in range(8)]
+    o = orc.OracleMap(force_float=force_float)
+    ref = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float)
+    shards = [pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, shard_rank=r, shard_count=8, shard_block=2) for r in range(8)]
     for m in [o, ref] + shards:
         assert m.prepare(wl.IDENTITY_PLANE, cam, poses)
     for k, p in enumerate(poses):
@@ -37,6 +38,35 @@ def test_cfg2_eight_way_sharding_at_full_frame_size(pf, orc):
         assert rs["level0_px"] < 3.0 * rs["owned_px"]                   # a shard renders its cells + halo, not the whole canvas
     assert got == dref and len(ref.tiles()) >= 300
     assert sum(1 for m in shards if m.tiles()) == 8
+
+
+@pytest.mark.parametrize("force_float", [1, 0])
+def test_cfg2_timed_path_two_flight_lines_against_oracle(pf, orc, force_float):
+    """The path bench.py times (device-resident 4000x3000 keyframes through pf_feed_device, fused = 1, cfg-A) against the ORACLE
+    over several keyframes: two flight lines of the serpentine (forward AND side overlap, yaw / tilt jitter), so that the
+    max-weight select runs on most pixels with real stored weights, level by level (MultiBandMap2DCPU.cpp:476-555); then
+    Ele::blend on tiles whose 3x3 neighbourhood exists and the whole-mosaic save."""
+    torch = pytest.importorskip("torch")
+    wl = workloads()
+    cam = [4000, 3000, 3000, 3000, 2000, 1500]
+    poses = wl.serpentine(cam, 100.0, 8, per_row=4)                      # out along one line, back along the next
+    host = [wl.noise_frame(3000, 4000, 60 + k) for k in range(3)]
+    dev = [torch.from_numpy(f).cuda() for f in host]
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, fused=1)
+    o = orc.OracleMap(force_float=force_float)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        assert g.feed_device(dev[k % 3].data_ptr(), 3000, 4000, p) and o.feed(host[k % 3], p)
+    assert g.sync() and g.grid() == o.grid()
+    assert compare_maps(g, o) == []
+    tiles = o.tiles()
+    have = set(tiles)
+    inner = [t for t in tiles if all((t[0] + dx, t[1] + dy) in have for dx in (-1, 0, 1) for dy in (-1, 0, 1))]
+    assert len(tiles) > 400 and len(inner) > 200
+    for t in [inner[0], inner[len(inner) // 3], inner[2 * len(inner) // 3], inner[-1]]:
+        assert np.array_equal(g.blend_tile(*t), o.blend_tile(*t)), t
+    assert np.array_equal(g.save_to_memory()[0], o.save()[0])
+    g.close()
 
 
 def test_cfg4_65536_tile_store_and_7band_frames(pf, orc):

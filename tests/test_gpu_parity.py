@@ -282,6 +282,21 @@ def test_degenerate_frame_shapes(pf, orc, shape):
         assert np.array_equal(s.tile_bgra(*t), so.tile_bgra(*t))
 
 
+@pytest.mark.parametrize("weight_type", [0, 1])
+def test_frame_wider_than_8191_px(pf, orc, weight_type):
+    """A frame with a side of 8192 px or more: the radial weight's squares (dx^2, |dx| up to 4128) no longer fit 24 bits, so the
+    computed form of weightImage (one fused rounding) would differ from the reference's two roundings (MultiBandMap2DCPU.cpp:411)
+    by an ulp now and then and flip max-weight selects.  Such frames gather the weight from the plane instead."""
+    wl = workloads()
+    w, h = 8256, 96
+    cam = [w, h, 9000.0, 9000.0, w / 2, h / 2]
+    poses = [[k * 7.0, k * 0.3, -100.0] + wl.quat_axis((0, 0, 1), 0.01 * k) for k in range(3)]
+    frames = [wl.noise_frame(h, w, 300 + k) for k in range(3)]
+    g, o = run_pair(pf, orc, cam, poses, frames, band_number=3, weight_type=weight_type)
+    assert compare_maps(g, o) == []
+    g.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_float", [0, 1])
 def test_general_coordinate_forms(force_float):
