@@ -1539,8 +1539,8 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
     static const int on = getenv("PF_STRIPS") ? atoi(getenv("PF_STRIPS")) : 0;      // default off until it beats the block form (profiles/r04_strips.md)
     static const int sablate = getenv("PF_SABLATE") ? atoi(getenv("PF_SABLATE")) : 0;      // timing only: 1 no warp, 2 no pyrDown, 4 no select, 8 no weight prefetch
     static const bool stamp = getenv("PF_STAMP") != nullptr;
-    static const bool other = getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") ||
-                              getenv("PF_INTERLEAVE_JOBS") || getenv("PF_UPPER_FIRST") || getenv("PF_A_ILP");
+    static const bool other = getenv("PF_WEIGHT_PLANE") || getenv("PF_PATCH") || getenv("PF_BLOCK64") || getenv("PF_ABLATE") || getenv("PF_A_ILP");
+    static const int order = getenv("PF_UPPER_FIRST") ? 2 : (getenv("PF_INTERLEAVE_JOBS") ? 0 : 1);
     if (!on || other) return false;
     if (wa && !radial_weight_exact(*wa)) return false;
     constexpr int R = 4;
@@ -1572,7 +1572,7 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
     }
     if (!batch.njobs) return true;
     const int nblocks = first_blocks + upper_blocks;
-    batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8; batch.sequential = 1;
+    batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8; batch.sequential = order;
     FusedWarp w{};
     if (wa) {
         for (int i = 0; i < 9; i++) w.M[i] = wa->M[i];
