@@ -1666,6 +1666,14 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // warped pixel instead of three.  Measured on MI355X (profiles/r03_ab.md): fp32 +1.8 %, int16 +-0 against the weight
     // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
     static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
+    if (wa && !wplane && !st && BH == 28 && radial_weight_exact(*wa)) {
+        // PF_BLOCK28 (A/B): 64x28 blocks stage 35 rows = five whole passes of the 7 rows 512 threads warp at a time (a 64x32 block
+        // stages 39 rows in six passes: 42 row slots for 39 rows)
+        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
+        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 28, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        else         hipLaunchKernelGGL((k_levels<false, 28, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        return;
+    }
     if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2) && radial_weight_exact(*wa)) {
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
         if (lay.f32) {
@@ -1677,6 +1685,9 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         }
         return;
     }
+    if (BH == 28) {
+        if (lay.f32) PF_GO(true, 28, 512, false, 3); else PF_GO(false, 28, 512, false, 2);
+    } else
     if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)
         if (lay.f32) { if (ilp == 3) PF_GO(true, 64, 1024, false, 3); else PF_GO(true, 64, 1024, false, 2); }
         else if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);
@@ -1693,9 +1704,9 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
 // Measured on MI355X, cfg-A: int16 -23 %, fp32 -18 %
 int level_block_rows(bool f32)
 {
-    static const bool b64 = getenv("PF_BLOCK64") != nullptr;
+    static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr;
     (void)f32;
-    return b64 ? 64 : 32;
+    return b64 ? 64 : (b28 ? 28 : 32);
 }
 
 // diagnostics: the stamps of the most recent PF_STAMP launch (8 u64 per workgroup: start, A done, barrier 1 passed, B done,

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Predicted strong scaling of the tile-sharded mosaic from ONE GPU (no multi-GPU node has run this code yet).
+
+For N in {2, 4, 8} ranks and spatial-hash cells of {2, 4, 8} tiles, every rank's shard of the cfg-A sortie (200 keyframes timed
+after 20, bench.py's workload, device-resident frames) is run ALONE on this GPU -- on a node each rank has a GPU to itself and
+`feed` has no collective, so a rank's time on the node is its time here.  Predicted keyframes/s = K / max over ranks.
+Added from the library's own exchange plan (pf_dist_plan_blend, a pure function of the tile lists; no bytes move here):
+  * the seam bytes every rank receives for ONE full redraw (draw() of all tiles) and the time that takes over xGMI at
+    153 GB/s per link and direction with min(N-1, 7) links per GPU busy;
+  * the bytes pf_dist_feed moves per keyframe: 36 MB to every rank, other than the root, that owns a tile of the canvas.
+usage: python tools/predict_scaling.py [--int16] [--frames 200] [--warm 20] [--md out.md]
+Semantics reproduced across ranks: MultiBandMap2DCPU.cpp:724-741 (neighbour gather), :806-836 (paste + single collapse)."""
+import argparse, importlib, json, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import bench
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--int16", action="store_true"); ap.add_argument("--frames", type=int, default=200); ap.add_argument("--warm", type=int, default=20)
+ap.add_argument("--ranks", default="2,4,8"); ap.add_argument("--cells", default="2,4,8"); ap.add_argument("--md", default=None)
+a = ap.parse_args()
+pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")
+sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+cam = bench.CAM
+K, W = a.frames, a.warm
+poses = wl.serpentine(cam, 100.0, K + W)
+fr = [torch.randint(0, 256, (cam[1], cam[0], 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
+torch.cuda.synchronize()
+ff = 0 if a.int16 else 1
+LINK = 153e9
+FRAME_BYTES = cam[0] * cam[1] * 3
+
+
+def run(rank, n, cell):
+    kw = dict(force_float=ff)
+    if n > 1:
+        kw.update(shard_rank=rank, shard_count=n, shard_block=cell)
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, **kw)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
+    m.reserve_tiles(2800 // n + 500)
+    for k in range(W):
+        assert m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k]) in (True, False)
+    m.sync(); torch.cuda.synchronize()
+    rs0 = m.render_stats()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k])
+    m.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rs = m.render_stats()
+    tiles = m.tiles()
+    hb9 = [m.halo_bytes(dx, dy) if (dx, dy) != (0, 0) else 0 for (dx, dy) in sh.NEIGHBOURS]
+    m.close()
+    return {"s": dt, "frames_with_pixels": rs["frames_with_pixels"] - rs0["frames_with_pixels"],
+            "level0_px": rs["level0_px"] - rs0["level0_px"], "owned_px": rs["owned_px"] - rs0["owned_px"], "tiles": tiles, "hb9": hb9}
+
+
+base = run(0, 1, 0)
+base_kfs = K / base["s"]
+rows = []
+print("unsharded: %.1f keyframes/s (%.1f us per keyframe), %d tiles" % (base_kfs, base["s"] / K * 1e6, len(base["tiles"])), flush=True)
+for n in [int(v) for v in a.ranks.split(",")]:
+    for cell in [int(v) for v in a.cells.split(",")]:
+        rk = [run(r, n, cell) for r in range(n)]
+        tmax = max(r["s"] for r in rk)
+        lists = [[(ix, iy, 1) for (ix, iy) in r["tiles"]] for r in rk]
+        caps = [len(l) + 1 for l in lists]
+        recv_b, strips = [], 0
+        for me in range(n):
+            _, recv, _ = sh.plan_blend(lists, caps, me, True, rk[0]["hb9"])
+            # bytes of a received strip set = halo_bytes of its direction
+            recv_b.append(sum(rk[0]["hb9"][3 * (q["dy"] + 1) + (q["dx"] + 1)] for q in recv)); strips += len(recv)
+        links = min(n - 1, 7)
+        seam_ms = max(recv_b) / (links * LINK) * 1e3
+        # pf_dist_feed: one H2D on the root, then one copy to every other rank that owns a tile of the canvas
+        needers = sum(r["frames_with_pixels"] for r in rk)
+        p2p_per_kf = max(0.0, (needers - K * 1.0 / n * 0)) / K       # ranks with pixels per keyframe (the root is one of them 1/n of the time)
+        p2p_bytes = max(0.0, p2p_per_kf - 1.0) * FRAME_BYTES if n > 1 else 0.0
+        rec = {"ranks": n, "cell": cell, "rank_seconds": [round(r["s"], 4) for r in rk], "predicted_kfs": round(K / tmax, 1),
+               "speedup": round(K / tmax / base_kfs, 2), "efficiency": round(K / tmax / base_kfs / n, 3),
+               "halo_factor": [round(r["level0_px"] / max(r["owned_px"], 1.0), 3) for r in rk],
+               "frames_with_pixels": [r["frames_with_pixels"] for r in rk], "tiles": [len(r["tiles"]) for r in rk],
+               "seam_bytes_total": int(sum(recv_b)), "seam_bytes_max_rank": int(max(recv_b)), "seam_strips": strips, "seam_ms_xgmi": round(seam_ms, 3),
+               "ranks_with_pixels_per_keyframe": round(p2p_per_kf, 2), "feed_p2p_bytes_per_keyframe": int(p2p_bytes),
+               "feed_p2p_us_per_keyframe": round(p2p_bytes / max(links, 1) / LINK * 1e6, 1)}
+        rows.append(rec)
+        print(json.dumps(rec), flush=True)
+if a.md:
+    with open(a.md, "w") as f:
+        f.write("| ranks | cell (tiles) | predicted kf/s | speed-up | efficiency | slowest / fastest rank (ms per 200 kf) | halo factor (max) | ranks with pixels per kf | "
+                "seam bytes, full redraw (max rank) | seam time over xGMI | feed P2P per kf |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("| 1 | -- | %.0f | 1.00 | 1.000 | %.1f | 1.0 | 1 | -- | -- | -- |\n" % (base_kfs, base["s"] * 1e3))
+        for r in rows:
+            f.write("| %d | %d | %.0f | %.2f | %.3f | %.1f / %.1f | %.2f | %.2f | %.1f MB (%.1f MB) | %.2f ms | %.1f MB, %.0f us |\n" % (
+                r["ranks"], r["cell"], r["predicted_kfs"], r["speedup"], r["efficiency"], max(r["rank_seconds"]) * 1e3, min(r["rank_seconds"]) * 1e3,
+                max(r["halo_factor"]), r["ranks_with_pixels_per_keyframe"], r["seam_bytes_total"] / 1e6, r["seam_bytes_max_rank"] / 1e6, r["seam_ms_xgmi"],
+                r["feed_p2p_bytes_per_keyframe"] / 1e6, r["feed_p2p_us_per_keyframe"]))
