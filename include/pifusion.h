@@ -95,6 +95,9 @@ long    pf_debug_read_last_frame(pf_map* m, void* out, size_t cap);
 /* Diagnostics (PF_STAMP=1 selects a stamped instantiation of the level kernel; tools/stamp_phases.py): in-kernel clock
  * stamps of the most recent launch, 8 uint64 per workgroup.  Returns the workgroup count.                            */
 int     pf_debug_phase_stamps(unsigned long long* out, int cap_blocks);
+/* PF_STAMP=1 builds only: per pyramid level, pixels the max-weight select looked at (out[2*level]) and pixels that won
+ * (out[2*level+1]) since the last reset; out holds 18 values.  Counts the useful tile bytes of a launch. */
+int     pf_debug_select_counts(unsigned long long* out, int reset);
 /* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
 unsigned pf_queue_size(pf_map* m);
 /* drain the feed queue and the device stream (no reference counterpart:

@@ -843,6 +843,10 @@ __device__ __forceinline__ void phase_stamp(unsigned long long* st, int slot)
     }
 }
 
+// diagnostic build only (PF_STAMP=1, tools/count_wins.py): per level, pixels stage D looked at / pixels that won the max-weight select --
+// the USEFUL tile bytes of a launch are wins x (12 + 4) (fp32), whatever WRITE_SIZE says about sectors
+__device__ unsigned long long g_select_seen[kMaxLevels], g_select_won[kMaxLevels];
+
 // bytes of LDS a PATCH workgroup has behind A for the source patch (Bt lives there after stage A): two workgroups per CU
 constexpr int kPatchBytes = 81920 - 44928;
 
@@ -1237,6 +1241,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
     const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
     const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
+    if constexpr (STAMP) {
+        atomicAdd(&g_select_seen[g.level], (unsigned long long)(1 + (int)in01 + (int)in10 + (int)(in10 && in01)));
+        atomicAdd(&g_select_won[g.level], (unsigned long long)((int)s00 + (int)s01 + (int)s10 + (int)s11));
+    }
     if (!(s00 || s01 || s10 || s11)) return;
     const int sy = dy0 >> 1, sx = dx0 >> 1;
     int syn = sy + 1; if (syn >= nrows) syn = nrows - 1;
@@ -1707,6 +1715,20 @@ int level_block_rows(bool f32)
     static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr;
     (void)f32;
     return b64 ? 64 : (b28 ? 28 : 32);
+}
+
+// diagnostics (PF_STAMP=1): pixels seen / won by stage D per level since the last reset; out[2 * level] = seen, [2 * level + 1] = won
+int read_select_counts(unsigned long long* out, int reset)
+{
+    unsigned long long seen[kMaxLevels], won[kMaxLevels];
+    if (hipMemcpyFromSymbol(seen, HIP_SYMBOL(g_select_seen), sizeof seen) != hipSuccess) return 0;
+    if (hipMemcpyFromSymbol(won, HIP_SYMBOL(g_select_won), sizeof won) != hipSuccess) return 0;
+    for (int i = 0; i < kMaxLevels; i++) { out[2 * i] = seen[i]; out[2 * i + 1] = won[i]; }
+    if (reset) {
+        unsigned long long z[kMaxLevels] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_select_seen), z, sizeof z); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_select_won), z, sizeof z);
+    }
+    return kMaxLevels;
 }
 
 // diagnostics: the stamps of the most recent PF_STAMP launch (8 u64 per workgroup: start, A done, barrier 1 passed, B done,

@@ -96,6 +96,7 @@ struct LevelLaunch {
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);
+int  read_select_counts(unsigned long long* out, int reset);       // diagnostics (PF_STAMP=1): [2*level] pixels stage D saw, [2*level+1] pixels that won
 int  level_block_rows(bool f32);                                     // block height of the pipelined level kernel (fused = 1)      // diagnostics (PF_STAMP=1)
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
