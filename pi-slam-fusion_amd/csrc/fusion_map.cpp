@@ -683,13 +683,32 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
     Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
     const bool sharded = opt_.shard_count > 1;
+    // Cull (round 4): a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- its
+    // table entry stays 0, exactly as if another shard owned it, and the need rectangles below shrink the grid to what the
+    // remaining tiles depend on.  Nothing changes in what is stored: `if (srcW >= dstW)` (.cpp:521, :542) is false at every pixel
+    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (tile_weight_bounds):
+    //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the tile dilated by the pyramid's
+    //                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
+    //   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
+    //                 dilated tile, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
+    //                 then S_i > W_i^f.  Tile::wlb = max over f of wmin_f.
+    // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
+    static const bool cull_env = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
+    double Minv[9];
+    const bool cull = cull_env && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
+    const float cull_r = (float)(2 << L);                        // pyramid support radius in level-0 pixels (2^(L+1) - 2, rounded up)
+    std::vector<std::pair<Tile*, float>> raise;                  // (tile, wmin of this keyframe): applied once the frame is in
+    bool culled_any = false;
     struct Cell { int cx, cy, x0, y0, x1, y1; };
     Cell cells[64]; int ncells = 0; bool cells_overflow = false;
     const int B = opt_.shard_block;
+    // cells of the need rectangles: a shard's hash cells; for the cull alone squares of 8 x 8 tiles as well (PF_CULL_CELL, A/B)
+    static const int bc_env = std::getenv("PF_CULL_CELL") ? std::atoi(std::getenv("PF_CULL_CELL")) : 0;
+    const int Bc = sharded ? B : (bc_env > 0 ? bc_env : 8);      // measured (profiles/r04_ab.md): 8 beats 3 / 4 (fewer, tighter-merging rectangles; less host work)
     table_tmp_.resize((size_t)tx * ty);
     std::vector<Tile*> touched;
     touched.reserve((size_t)tx * ty);
-    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0;
+    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0, owned_all = 0;
     for (int y = 0; y < ty; y++) {
         const int sy = yminInt + y + off_y_;
         for (int x = 0; x < tx; x++) {
@@ -698,12 +717,20 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             if (!sharded || tile_owner(opt_.shard_count, B, sx, sy) == opt_.shard_rank) {
                 Tile* t = store_.get_or_create(sx, sy);
                 if (!t) return false;
+                owned_all++;
+                if (cull) {
+                    float wmax, wmin;
+                    tile_weight_bounds(Minv, f.cols, f.rows, opt_.weight_type, x * kElePixels - cull_r, y * kElePixels - cull_r,
+                                       (x + 1) * kElePixels + cull_r, (y + 1) * kElePixels + cull_r, &wmax, &wmin);
+                    if (wmin > t->wlb) raise.push_back({ t, wmin });
+                    if (!t->fresh && wmax < t->wlb) { culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; continue; }
+                }
                 ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
                 touched.push_back(t);
                 owned++;
                 bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
-                if (sharded && !cells_overflow) {
-                    const int cx = floordiv(sx, B), cy = floordiv(sy, B);
+                if ((sharded || cull) && !cells_overflow) {
+                    const int cx = floordiv(sx, Bc), cy = floordiv(sy, Bc);
                     int k = ncells - 1;
                     while (k >= 0 && !(cells[k].cx == cx && cells[k].cy == cy)) k--;
                     if (k < 0) {
@@ -718,7 +745,11 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             table_tmp_[(size_t)y * tx + x] = ent;
         }
     }
-    if (bx0 >= bx1) return true;                // nothing of this frame lands on this shard
+    if (bx0 >= bx1) {                           // nothing of this frame lands on this shard, or it cannot win anywhere it lands
+        for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
+        if (owned_all) n_rendered_++;
+        return true;
+    }
     px_owned_ += (double)owned * kElePixels * kElePixels;     // what this rank renders beyond its share: owned tile pixels vs the level-0 window (bench --shard strong)
     n_with_pixels_++;
 
@@ -835,8 +866,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         // applied per cell); blocks outside every rectangle exit at once.  (Unsharded: every block is needed, no rectangles.)
         BlockRect rects[kMaxLevels][kMaxRects];
         int nrect[kMaxLevels] = {};
-        double owned_tiles = owned, blocks_run0 = 0;
-        if (sharded && opt_.fused == 1 && !cells_overflow) {
+        double owned_tiles = owned_all, blocks_run0 = 0;          // algorithmic bytes: every canvas tile of this rank, culled or not
+        if ((sharded || culled_any) && opt_.fused == 1 && !cells_overflow) {
             const int BHr = level_block_rows(lay_.f32 != 0);
             struct R { int x0, y0, x1, y1; };
             std::vector<R> lv[kMaxLevels];
@@ -985,8 +1016,67 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     }
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
     for (Tile* t : touched) { t->fresh = false; t->changed = true; }
+    for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
     n_rendered_++;
     return true;
+}
+
+// May this frame's tiles be culled?  Only for a tame map: every canvas corner (with the pyramid halo) in front of the camera and
+// far inside the int range, as the kernels' fast path assumes -- anything else renders every tile.
+bool FusionMap::cull_frame_ok(const double M[9], int crows, int ccols) const
+{
+    const double xs[2] = { -600.0, ccols + 600.0 }, ys[2] = { -600.0, crows + 600.0 };
+    int sign = 0;
+    for (int i = 0; i < 4; i++) {
+        const double x = xs[i & 1], y = ys[i >> 1], W = M[6] * x + M[7] * y + M[8];
+        if (!(std::fabs(W) > 1e-12) || !std::isfinite(W)) return false;
+        const int sg = W > 0 ? 1 : -1;
+        if (sign && sg != sign) return false;
+        sign = sg;
+        if (!(std::fabs((M[0] * x + M[1] * y + M[2]) / W) < 1.0e7) || !(std::fabs((M[3] * x + M[4] * y + M[5]) / W) < 1.0e7)) return false;
+    }
+    return true;
+}
+
+// Bounds of the radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas
+// rectangle [x0,x1] x [y0,y1]: *wmax >= every weight the frame can have there, *wmin <= every weight it has there (0 unless the
+// rectangle maps wholly inside the frame).  The rectangle maps to a convex quadrilateral of the source plane (M is projective and W
+// keeps its sign, cull_frame_ok); the weight falls with the distance from the image centre, so the largest weight sits at the point
+// of the quadrilateral nearest to the centre and the smallest at its farthest corner.  Margins: 2 source pixels for the nearest-pixel
+// rounding (0.71) and the float arithmetic of the kernels, 1e-5 on the weight for the pyramid's own rounding.
+void FusionMap::tile_weight_bounds(const double M[9], int cols, int rows, int weight_type, double x0, double y0, double x1, double y1,
+                                   float* wmax, float* wmin)
+{
+    const double cx[4] = { x0, x1, x1, x0 }, cy[4] = { y0, y0, y1, y1 };
+    double qx[4], qy[4];
+    for (int i = 0; i < 4; i++) {
+        const double W = M[6] * cx[i] + M[7] * cy[i] + M[8];
+        qx[i] = (M[0] * cx[i] + M[1] * cy[i] + M[2]) / W; qy[i] = (M[3] * cx[i] + M[4] * cy[i] + M[5]) / W;
+    }
+    const double xc = (double)(cols / 2), yc = (double)(rows / 2), dis_max = std::sqrt(xc * xc + yc * yc);
+    bool inside_frame = true; double dfar = 0;
+    for (int i = 0; i < 4; i++) {
+        inside_frame = inside_frame && qx[i] >= 1.0 && qx[i] <= cols - 2.0 && qy[i] >= 1.0 && qy[i] <= rows - 2.0;
+        dfar = std::max(dfar, std::hypot(qx[i] - xc, qy[i] - yc));
+    }
+    // distance from the centre to the quadrilateral: 0 inside, else to the nearest edge
+    bool pos = true, neg = true; double dnear = 1e300;
+    for (int i = 0; i < 4; i++) {
+        const int j = (i + 1) & 3;
+        const double ex = qx[j] - qx[i], ey = qy[j] - qy[i], px = xc - qx[i], py = yc - qy[i];
+        const double cr = ex * py - ey * px;
+        pos = pos && cr >= 0; neg = neg && cr <= 0;
+        const double e2 = ex * ex + ey * ey;
+        double t = e2 > 0 ? (px * ex + py * ey) / e2 : 0.0;
+        t = t < 0 ? 0 : (t > 1 ? 1 : t);
+        dnear = std::min(dnear, std::hypot(px - t * ex, py - t * ey));
+    }
+    if (pos || neg) dnear = 0;
+    auto weight = [&](double d) { double w = 1.0 - d / dis_max; if (weight_type != 0) w = w > 0 ? w * w : 0.0; return w; };
+    const double hi = weight(std::max(0.0, dnear - 2.0)) + 1e-5;
+    *wmax = (float)std::max(hi, 2e-5);                                       // inside the frame a weight is never below 1e-5
+    const double lo = inside_frame ? weight(dfar + 2.0) - 1e-5 : 0.0;
+    *wmin = lo > 2e-5 ? (float)lo : 0.f;
 }
 
 // Retirement without an event per frame (see the header): count the submission, drop a marker now and then.
@@ -1185,7 +1275,7 @@ bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
     if (!t) return false;
     HIP_OK(hipMemcpyAsync(t->base, dev_in, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
     HIP_OK(sync_all());
-    t->fresh = false; t->changed = true;
+    t->fresh = false; t->changed = true; t->wlb = -1.f;          // imported pixels: nothing known about their weights
     return true;
 }
 

@@ -27,6 +27,9 @@ struct Tile {
     char* base = nullptr;   // slot base in HBM
     bool  fresh = true;     // pyr_laplace[i].empty() (.cpp:498): first write copies unconditionally
     bool  changed = false;  // Ele::Ischanged
+    // A lower bound of every weight stored in this tile, all levels (render_frame's cull): each keyframe whose canvas holds the
+    // tile raises it to the smallest weight that keyframe can have anywhere in the tile's pyramid support.  <= 0: nothing known.
+    float wlb = -1.f;
 };
 
 class TileStore {
@@ -116,6 +119,10 @@ public:
     // draw()'s Fuse2Google gate and operands for tile (ix, iy) (MultiBandMap2DCPU.cpp:709-712, :730-735, :744): false when the tile
     // has no pyramid, or lies on the rim of the dense grid while HighQualityShow is on
     bool map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y);
+    // the cull of render_frame (tiles in which a keyframe cannot win the select): see there
+    bool cull_frame_ok(const double M[9], int crows, int ccols) const;
+    static void tile_weight_bounds(const double M[9], int cols, int rows, int weight_type, double x0, double y0, double x1, double y1, float* wmax, float* wmin);
+    long long culled_tiles() const { return n_culled_tiles_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
     int  num_levels() const { return band_num_ + 1; }
@@ -175,6 +182,7 @@ private:
     std::mutex mu_;
     bool   valid_ = false;
     Pose   plane_{}, plane_inv_{};
+    long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
     double min_[3]{}, max_[3]{};

@@ -1374,7 +1374,7 @@ struct LevelJob {
 };
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
 // in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
@@ -1399,7 +1399,9 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
     const LevelJob& J = batch.job[j];
     const int nblk = J.g.nbx * J.g.nby;
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
-    const int bb = xcd_order(b, nblk);
+    // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
+    // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
+    const int bb = (J.nrect && !batch.rect_runs) ? b : xcd_order(b, nblk);
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
     // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
@@ -1641,6 +1643,8 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
     static const bool upper_first = getenv("PF_UPPER_FIRST") != nullptr;
     batch.sequential = upper_first ? 2 : !interleave;
+    static const bool rect_runs = getenv("PF_RECT_ORDER") != nullptr;
+    batch.rect_runs = rect_runs;
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {
