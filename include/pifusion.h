@@ -264,6 +264,9 @@ int     pf_render_stats(pf_map* m, double out4[4]);
  * time is pf_profile_read's).  With PF_ROCTX=1 in the environment every section is also a roctx range.  Returns the count. */
 int     pf_timer_read(pf_map* m, int cap, const char** names, long long* calls, double* mean_s, double* min_s, double* max_s);
 int     pf_timer_reset(pf_map* m);
+/* Tiles left out of launches so far because the keyframe fed could not win the max-weight select anywhere in them (the cull of
+ * render_frame: bounds from the geometry alone; results are those of the full render, PF_CULL=0 switches it off). Diagnostics. */
+long long pf_debug_culled_tiles(pf_map* m);
 /* frames rendered / rejected since creation */
 int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
 /* Allocator hint, no reference counterpart (MultiBandMap2DCPUEle's cv::Mat tiles, MultiBandMap2DCPU.h:32-51,

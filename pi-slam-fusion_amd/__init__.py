@@ -124,6 +124,7 @@ def lib():
     L.pf_profile_reset.argtypes = [vp]
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
+    L.pf_debug_culled_tiles.argtypes = [vp]; L.pf_debug_culled_tiles.restype = C.c_longlong
     L.pf_render_stats.argtypes = [vp, dp]
     L.pf_timer_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp, dp]
     L.pf_timer_reset.argtypes = [vp]
@@ -399,6 +400,10 @@ class Map2D:
 
     def timer_reset(self):
         lib().pf_timer_reset(self._h)
+
+    def culled_tiles(self):
+        """tiles left out of launches because the keyframe could not win the select anywhere in them (diagnostics)"""
+        return int(lib().pf_debug_culled_tiles(self._h))
 
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

@@ -698,6 +698,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     const bool cull = cull_env && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
     const float cull_r = (float)(2 << L);                        // pyramid support radius in level-0 pixels (2^(L+1) - 2, rounded up)
     std::vector<std::pair<Tile*, float>> raise;                  // (tile, wmin of this keyframe): applied once the frame is in
+    std::vector<Tile*> culled;
     bool culled_any = false;
     struct Cell { int cx, cy, x0, y0, x1, y1; };
     Cell cells[64]; int ncells = 0; bool cells_overflow = false;
@@ -723,7 +724,12 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                     tile_weight_bounds(Minv, f.cols, f.rows, opt_.weight_type, x * kElePixels - cull_r, y * kElePixels - cull_r,
                                        (x + 1) * kElePixels + cull_r, (y + 1) * kElePixels + cull_r, &wmax, &wmin);
                     if (wmin > t->wlb) raise.push_back({ t, wmin });
-                    if (!t->fresh && wmax < t->wlb) { culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; continue; }
+                    if (!t->fresh && wmax < t->wlb) {
+                        // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
+                        // (.cpp:553), and draw() re-blends it with whatever its neighbours have become
+                        culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; culled.push_back(t);
+                        continue;
+                    }
                 }
                 ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
                 touched.push_back(t);
@@ -747,6 +753,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     }
     if (bx0 >= bx1) {                           // nothing of this frame lands on this shard, or it cannot win anywhere it lands
         for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
+        for (Tile* t : culled) t->changed = true;
         if (owned_all) n_rendered_++;
         return true;
     }
@@ -1016,6 +1023,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     }
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
     for (Tile* t : touched) { t->fresh = false; t->changed = true; }
+    for (Tile* t : culled) t->changed = true;
     for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
     n_rendered_++;
     return true;

@@ -1401,7 +1401,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
     // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
     // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
-    const int bb = (J.nrect && !batch.rect_runs) ? b : xcd_order(b, nblk);
+    const int bb = ((J.nrect && !batch.rect_runs) || batch.rect_runs == 2) ? b : xcd_order(b, nblk);
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
     // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
@@ -1643,7 +1643,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
     static const bool upper_first = getenv("PF_UPPER_FIRST") != nullptr;
     batch.sequential = upper_first ? 2 : !interleave;
-    static const bool rect_runs = getenv("PF_RECT_ORDER") != nullptr;
+    static const int rect_runs = getenv("PF_RECT_ORDER") ? atoi(getenv("PF_RECT_ORDER")) : 0;      // 1: XCD runs even with rectangles; 2: round robin always (A/B)
     batch.rect_runs = rect_runs;
     if (!batch.njobs) return;
     FusedWarp w{};

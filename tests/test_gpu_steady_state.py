@@ -133,3 +133,34 @@ def test_bench_sortie_pipelined_equals_per_op(pf):
         del m
     assert len(digests[0]) > 1000 * 6
     assert digests[0] == digests[1]
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_cull_leaves_results_and_changed_flags_alone(pf, orc, force_float):
+    """The cull (tiles in which a keyframe cannot win the max-weight select at any level are left out of the launch) against
+    the oracle, which renders every tile of every canvas: same pyramids, same blends -- and the tiles draw() is told about
+    are still ALL tiles of the keyframe's canvas (Apply sets Ischanged on each, MultiBandMap2DCPU.cpp:553), culled or not.
+    Map2D.Scale = 2.5 makes a keyframe's canvas ~11 x 9 tiles, so that whole tiles lie on the losing side of a neighbour."""
+    wl = workloads()
+    poses = sortie(40, seed=5)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, fused=1, scale=2.5)
+    o = orc.OracleMap(force_float=force_float, scale=2.5)
+    assert g.prepare(wl.IDENTITY_PLANE, CAM, poses[:12]) and o.prepare(wl.IDENTITY_PLANE, CAM, poses[:12])
+    for k, p in enumerate(poses):
+        assert g.feed(frame(k), p) and o.feed(frame(k), p)
+    assert g.sync()
+    culled = g.culled_tiles()
+    assert culled > 40, culled                                    # the cull did take tiles out, many of them
+    assert compare_maps(g, o) == []
+    g.blend_changed(cap=8192)                                     # draw(): clears the flags
+    # one more keyframe a little beside the last one: it loses wherever the last one is closer, yet its whole canvas is flagged
+    extra = list(poses[-1]); extra[0] += 6.0
+    assert g.feed(frame(61), extra) and o.feed(frame(61), extra) and g.sync()
+    assert g.culled_tiles() > culled
+    coords, px = g.blend_changed(cap=8192)
+    xs = sorted(set(c[0] for c in coords)); ys = sorted(set(c[1] for c in coords))
+    assert len(coords) == len(xs) * len(ys) >= 40 and xs == list(range(xs[0], xs[-1] + 1)) and ys == list(range(ys[0], ys[-1] + 1))
+    assert compare_maps(g, o) == []
+    for (ix, iy), img in list(zip(coords, px))[:: max(1, len(coords) // 8)]:
+        assert np.array_equal(img, o.blend_tile(ix, iy)), (ix, iy)
+    g.close()
