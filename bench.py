@@ -17,6 +17,9 @@ per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
                  carries the per-rank halo-recompute factor and the timed seam exchange (blend of
                  all tiles with neighbour strips from other ranks, gather + save on rank 0).
 
+`value` is the device-resident rate: keyframes already in HBM, fed through pf_feed_device.  What a tracker feeding host frames
+gets per GPU is the `host_feed` record of the same line (pf_feed with its 36 MB H2D copy inside: PCIe-bound, ~1500 keyframes/s).
+
 Rank 0 prints ONE JSON line (contract in the task statement), including
   roofline     : dominant kernel, algorithmic bytes / HIP-event time on the map's stream
   cpu_baseline : the oracle (CPU port of MultiBandMap2DCPU) timed on a bounded sample.
@@ -327,7 +330,10 @@ def main():
                          "(default steps//8; each event pair costs stream time; 0 = none, no roofline)")
     ap.add_argument("--no-strong-probe", action="store_true", help="N > 1, --shard weak: skip the tile-sharded sub-measurement")
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 2)")
+    ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 8)")
+    ap.add_argument("--no-pre", action="store_true",
+                    help="do not fly the 20 - W keyframes of the sortie's first line before the warm-up: a short run then times that "
+                         "first line (every tile new, nothing culled), as round 2's driver record did")
     args = ap.parse_args()
 
     import torch
@@ -355,11 +361,11 @@ def main():
     K, W, N = args.steps, args.warmup, world
     ev_every = event_every_for(K, args.event_every)
     strong = args.shard == "strong" and N > 1
-    block = args.shard_block or (2 if strong else 128)
+    block = args.shard_block or (8 if strong else 128)          # cell 8: profiles/r04_predicted_scaling.md
     # SURVEY 8d / BASELINE.md cfg-2 times the keyframes AFTER the first 20 of the sortie (its first flight line, where every
     # tile is new).  A run with fewer warm-up steps than that (the driver's --steps 20 --warmup 5) flies the missing
     # 20 - W keyframes during setup, untimed, so that every K / W times the same part of the sortie: interior flight lines.
-    PRE = max(0, 20 - W)
+    PRE = 0 if args.no_pre else max(0, 20 - W)
     n_traj = K + W + PRE
     extra = {} if args.fused is None else {"fused": args.fused}
 
@@ -481,7 +487,10 @@ def main():
                        "tile_sharding": "none" if N == 1 else
                                         ("one sortie, tiles split by spatial hash, cell %d tiles" % block if strong else
                                          "replicas: one sortie per rank inside its own hash cell (cell %d tiles)" % block),
-                       "rendered_rank0": st["rendered"]},
+                       "rendered_rank0": st["rendered"],
+                       # tiles of the timed keyframes' canvases left out of the launches because the keyframe cannot win the max-weight
+                       # select anywhere in them (geometric bound, results identical to the full render; PF_CULL=0 renders them all)
+                       "culled_tiles_rank0": m.culled_tiles()},
             "roofline": guarded(roofline_record, dom, p, dkey, ev_every),
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},

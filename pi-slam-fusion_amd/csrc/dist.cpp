@@ -472,6 +472,9 @@ int DistMap::feed(const pf_image* img, const double pose7[7], int root)
     if (!img || !m_->use_device()) return -1;
     const int n = t_->nranks, me = t_->rank;
     if (root < 0 || root >= n) { set_error("pf_dist_feed: root out of range"); return -1; }
+    // a frame that does not match the camera is rejected as Map2D::feed rejects it: 0 on every rank (each sees the same
+    // description), before the grid is touched and before any collective
+    if (m_->reject_mismatched_frame(img)) return 0;
     std::vector<unsigned char> needs;
     bool ok_here = m_->frame_needs(pose7, needs) && (int)needs.size() == n;
     if (ok_here && me == root && !img->data) { set_error("pf_dist_feed: the root has no pixels"); ok_here = false; }

@@ -531,6 +531,20 @@ bool FusionMap::frame_needs(const double pose7[7], std::vector<unsigned char>& r
     return true;
 }
 
+// renderFrame's size / type gate (.cpp:319-323) for a frame that arrives through pf_dist_feed: true if the frame was rejected --
+// message and counter exactly as feed() has them, and nothing else touched (the reference returns before any geometry)
+bool FusionMap::reject_mismatched_frame(const pf_image* desc)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!valid_) return false;
+    if ((desc->type != PF_8UC3 && desc->type != PF_8UC4) || desc->cols != cam_.w || desc->rows != cam_.h) {
+        std::fprintf(stderr, "MultiBandMap2DCPU::renderFrame: frame.first.cols!=p->_camera.w||frame.first.rows!=p->_camera.h||frame.first.type()!=CV_8UC3\n");
+        n_rejected_++;
+        return true;
+    }
+    return false;
+}
+
 int FusionMap::stage_frame(const pf_image* desc, bool upload_host, void** dev, size_t* bytes)
 {
     std::lock_guard<std::mutex> l(mu_);

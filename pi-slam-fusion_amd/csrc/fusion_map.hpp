@@ -109,6 +109,7 @@ public:
     // only; applies spreadMap exactly as feed() would, so a later feed of the same pose finds the grid as it left it),
     // a staging slot in HBM for the frame (filled from the host on the root, by the transport elsewhere), and the render
     // of a staged frame
+    bool reject_mismatched_frame(const pf_image* desc);      // Map2D::feed's size / type rejection, identical on every rank
     bool frame_needs(const double pose7[7], std::vector<unsigned char>& rank_needs);
     int  stage_frame(const pf_image* desc, bool upload_host, void** dev, size_t* bytes);     // slot index, -1 on failure
     bool feed_staged(int slot, const pf_image* desc, const double pose7[7]);                 // slot < 0: geometry-only feed

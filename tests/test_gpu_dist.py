@@ -279,6 +279,12 @@ def test_dist_feed_from_one_rank(pf, orc, world, force_float, root):
             st = dms[r].stats()
             moved += st["bytes_received"] + st["bytes_sent"]
         assert dms[r].feed(frames[0] if r == root else None, oblique, root=root, shape=frames[0].shape) is False   # rejected alike
+        # a frame that does not match the camera: rejected as Map2D::feed rejects it (.cpp:319-323) -- False on every rank, counted,
+        # the grid untouched -- not an error of the exchange
+        grid0, rej0 = maps[r].grid(), maps[r].stats()["rejected"]
+        small = frames[0][:100, :200]
+        assert dms[r].feed(np.ascontiguousarray(small) if r == root else None, poses[0], root=root, shape=small.shape) is False
+        assert maps[r].grid() == grid0 and maps[r].stats()["rejected"] == rej0 + 1
         assert maps[r].sync()
         return moved
     for f, p in zip(frames, poses):
