@@ -59,6 +59,7 @@ int pf_prepare(pf_map* m, const double plane[7], const double cam[6], int n, con
 int pf_feed(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, false); }
 int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, true); }
 int pf_debug_phase_stamps(unsigned long long* out, int cap_blocks) { return pf::read_phase_stamps(out, cap_blocks); }
+void pf_debug_form_counts(long long out[8]) { if (out) pf::read_form_counts(out); }
 long long pf_debug_culled_tiles(pf_map* m) { return m ? m->impl.culled_tiles() : 0; }
 int pf_debug_select_counts(unsigned long long* out, int reset) { return out ? pf::read_select_counts(out, reset) : 0; }
 long pf_debug_read_last_frame(pf_map* m, void* out, size_t cap) { return m ? m->impl.read_back_last_frame(out, cap) : -1; }

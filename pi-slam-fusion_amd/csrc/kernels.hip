@@ -1542,6 +1542,12 @@ static unsigned long long* g_stamp_buf = nullptr;
 static int g_stamp_blocks = 0;
 constexpr int kStampBlocks = 1 << 16;
 
+// launches of the pipelined level kernel by form since the library was loaded (tests/test_gpu_variants.py asserts that the form a
+// switch asks for really ran): 0 block form, computed weight (default); 1 block form, weight plane gather; 2 LDS-staged source patch;
+// 3 rolling strips; 4 64x64 blocks; 5 64x28 blocks; 6 stamped instantiation; 7 tile table in the kernel arguments
+static long long g_form_counts[8] = {};
+void read_form_counts(long long out[8]) { for (int i = 0; i < 8; i++) out[i] = g_form_counts[i]; }
+
 // The wave-specialised rolling-strip form of the pipelined launch (strips.inc).  Returns false when this launch has to take
 // the block form (diagnostic builds, the gathered weight plane).
 static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
@@ -1592,6 +1598,8 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
     }
     constexpr int P = PF_S_P;
+    g_form_counts[3]++;
+    if (batch.tab0_n) g_form_counts[7]++;
     if (stamp) {
         // diagnostic build (tools/strip_roles.py): 32 u64 per workgroup -- per wave {cycles waiting at the period barriers, lifetime}, [30] job, [31] periods
         if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, (size_t)kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
@@ -1669,7 +1677,10 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     }
 #define PF_GO(F, H, T, S, I) hipLaunchKernelGGL((k_levels<F, H, T, S, I>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
     // level 0 with LDS-staged source patches when the frame's map allows it (patch_plan)
+    if (batch.tab0_n) g_form_counts[7]++;
+    if (st) g_form_counts[6]++;
     if (wa && !st && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
+        g_form_counts[2]++;
         if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
         else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
         return;
@@ -1679,6 +1690,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
     static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
     if (wa && !wplane && !st && BH == 28 && radial_weight_exact(*wa)) {
+        g_form_counts[5]++;
         // PF_BLOCK28 (A/B): 64x28 blocks stage 35 rows = five whole passes of the 7 rows 512 threads warp at a time (a 64x32 block
         // stages 39 rows in six passes: 42 row slots for 39 rows)
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
@@ -1687,6 +1699,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         return;
     }
     if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2) && radial_weight_exact(*wa)) {
+        g_form_counts[0]++;
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
         if (lay.f32) {
             if (ilp == 3) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
@@ -1697,6 +1710,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         }
         return;
     }
+    if (wa) g_form_counts[BH == 64 ? 4 : (BH == 28 ? 5 : 1)]++;
     if (BH == 28) {
         if (lay.f32) PF_GO(true, 28, 512, false, 3); else PF_GO(false, 28, 512, false, 2);
     } else

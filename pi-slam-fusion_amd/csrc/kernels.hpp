@@ -96,6 +96,7 @@ struct LevelLaunch {
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);
+void read_form_counts(long long out[8]);                          // launches of the pipelined kernel by form (kernels.hip, g_form_counts)
 int  read_select_counts(unsigned long long* out, int reset);       // diagnostics (PF_STAMP=1): [2*level] pixels stage D saw, [2*level+1] pixels that won
 int  level_block_rows(bool f32);                                     // block height of the pipelined level kernel (fused = 1)      // diagnostics (PF_STAMP=1)
 

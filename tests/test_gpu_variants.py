@@ -4,6 +4,9 @@ tests in a child process (the switches are read once per process):
   PF_WEIGHT_PLANE=1  radial weight gathered from the fp32 weight plane instead of computed
   PF_TABLE_COPY=1    tile tables staged and copied in the stream instead of travelling in the kernel arguments
   PF_A_ILP=2 / 3     two / three warp rows per step for both pyramid types (defaults: fp32 3, int16 2)
+  PF_STRIPS=1        the wave-specialised rolling-strip form (profiles/r04_strips.md)
+  PF_BLOCK28=1       64x28 blocks
+  PF_CULL=0          every tile of every canvas rendered (no cull)
 Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:311-558 (renderFrame)."""
 import os
 import subprocess
@@ -15,10 +18,40 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3"])
+# which counter of pf_debug_form_counts must (or must not) move under a switch: the parity run alone would also pass on a silent
+# fall-back to the default form
+FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
+        "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
+        "PF_CULL=0": "culled == 0 and c[0] > 0"}
+PROBE = """
+import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+import ctypes as C, numpy as np
+from helpers import workloads, jitter_poses, compare_maps
+from conftest import load_package
+from oracle import orc
+pf = load_package(); wl = workloads()
+cam = [640, 480, 500, 500, 320, 240]
+poses = jitter_poses(6, seed=3, yaw_deg=3.0, tilt_deg=1.0)        # nearly nadir: the homography the PATCH plan accepts
+g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, scale=2.5); o = orc.OracleMap(force_float=1, scale=2.5)
+assert g.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
+for k, p in enumerate(poses + poses):
+    img = wl.noise_frame(480, 640, k); assert g.feed(img, p) and o.feed(img, p)
+g.sync(); assert compare_maps(g, o) == []
+c = (C.c_longlong * 8)(); pf.lib().pf_debug_form_counts(c); c = list(c); culled = g.culled_tiles()
+print("forms", c, "culled", culled)
+assert %s, (c, culled)
+"""
+
+
+@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_STRIPS", "PF_BLOCK28", "PF_CULL=0"])
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
+    # the requested form really runs (and gives the oracle's tiles) ...
+    probe = PROBE % (ROOT, os.path.join(ROOT, "tests"), FORM[switch])
+    r = subprocess.run([sys.executable, "-c", probe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    # ... and passes the parity tests
     # fused=1 cases of the plumbing and perspective tests: both pyramid types, noise and smooth frames, 0..8 bands, spreadMap
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
            "-k", "(cfg1_plumbing or perspective_and_spread) and -1]"]
