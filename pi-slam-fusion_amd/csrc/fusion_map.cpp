@@ -700,21 +700,26 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // Cull (round 4): a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- its
     // table entry stays 0, exactly as if another shard owned it, and the need rectangles below shrink the grid to what the
     // remaining tiles depend on.  Nothing changes in what is stored: `if (srcW >= dstW)` (.cpp:521, :542) is false at every pixel
-    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (tile_weight_bounds):
+    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (quadrant_weight_bounds):
     //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the tile dilated by the pyramid's
     //                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
     //   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
     //                 dilated tile, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
-    //                 then S_i > W_i^f.  Tile::wlb = max over f of wmin_f.
+    //                 then S_i > W_i^f.  Tile::wlb[quadrant] = max over f of wmin_f.
     // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
     static const bool cull_env = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
     double Minv[9];
     const bool cull = cull_env && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
-    const float cull_r = (float)(2 << L);                        // pyramid support radius in level-0 pixels (2^(L+1) - 2, rounded up)
-    std::vector<std::pair<Tile*, float>> raise;                  // (tile, wmin of this keyframe): applied once the frame is in
+    // The unit of the cull is a QUADRANT of a tile (128 x 128 pixels), dilated by the pyramid's support radius 2^(L+1) - 2 pixels
+    // rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose four quadrants are all out is left out
+    // of the launch; otherwise the quadrants that are out travel as flag bits of its table entry and the kernels do not look at their
+    // pixels (kernels.hip, quadrant_culled), which may have been computed from input nobody produced.
+    struct Raise { Tile* t; int q; float w; };
+    std::vector<Raise> raise;                                    // (quadrant, wmin of this keyframe): applied once the frame is in
     std::vector<Tile*> culled;
+    if (cull) cull_lattice(Minv, crows, ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
     bool culled_any = false;
-    struct Cell { int cx, cy, x0, y0, x1, y1; };
+    struct Cell { int cx, cy, x0, y0, x1, y1; };              // hash cell; box of what is rendered in it, level-0 pixels
     Cell cells[64]; int ncells = 0; bool cells_overflow = false;
     const int B = opt_.shard_block;
     // cells of the need rectangles: a shard's hash cells; for the cull alone squares of 8 x 8 tiles as well (PF_CULL_CELL, A/B)
@@ -724,6 +729,22 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     std::vector<Tile*> touched;
     touched.reserve((size_t)tx * ty);
     int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0, owned_all = 0;
+    // the same box in level-0 pixels, around the quadrants that are rendered (== the tiles' box when nothing is culled); cells likewise
+    int pbx0 = 1 << 30, pbx1 = 0, pby0 = 1 << 30, pby1 = 0;
+    auto add_rect = [&](int sx, int sy, int x0, int y0, int x1, int y1) {
+        pbx0 = std::min(pbx0, x0); pbx1 = std::max(pbx1, x1); pby0 = std::min(pby0, y0); pby1 = std::max(pby1, y1);
+        if (!(sharded || cull) || cells_overflow) return;
+        const int cx = floordiv(sx, Bc), cy = floordiv(sy, Bc);
+        int k = ncells - 1;
+        while (k >= 0 && !(cells[k].cx == cx && cells[k].cy == cy)) k--;
+        if (k < 0) {
+            if (ncells == 64) cells_overflow = true;
+            else cells[ncells++] = Cell{ cx, cy, x0, y0, x1, y1 };
+        } else {
+            Cell& c = cells[k];
+            c.x0 = std::min(c.x0, x0); c.y0 = std::min(c.y0, y0); c.x1 = std::max(c.x1, x1); c.y1 = std::max(c.y1, y1);
+        }
+    };
     for (int y = 0; y < ty; y++) {
         const int sy = yminInt + y + off_y_;
         for (int x = 0; x < tx; x++) {
@@ -733,40 +754,39 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 Tile* t = store_.get_or_create(sx, sy);
                 if (!t) return false;
                 owned_all++;
+                unsigned out = 0;                                  // quadrants in which this keyframe cannot win
                 if (cull) {
-                    float wmax, wmin;
-                    tile_weight_bounds(Minv, f.cols, f.rows, opt_.weight_type, x * kElePixels - cull_r, y * kElePixels - cull_r,
-                                       (x + 1) * kElePixels + cull_r, (y + 1) * kElePixels + cull_r, &wmax, &wmin);
-                    if (wmin > t->wlb) raise.push_back({ t, wmin });
-                    if (!t->fresh && wmax < t->wlb) {
+                    for (int q = 0; q < 4; q++) {
+                        float wmax, wmin;
+                        quadrant_weight_bounds(4 * x + 2 * (q & 1), 4 * y + 2 * (q >> 1), opt_.weight_type, &wmax, &wmin);
+                        if (wmin > t->wlb[q]) raise.push_back(Raise{ t, q, wmin });
+                        if (!t->fresh && wmax < t->wlb[q]) out |= 1u << q;
+                    }
+                    if (out == 15u) {
                         // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
                         // (.cpp:553), and draw() re-blends it with whatever its neighbours have become
                         culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; culled.push_back(t);
                         continue;
                     }
+                    if (out) { culled_any = true; n_culled_quads_ += __builtin_popcount(out); }
                 }
-                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u);
+                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u) | (uint64_t)(out << 1);
                 touched.push_back(t);
                 owned++;
                 bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
-                if ((sharded || cull) && !cells_overflow) {
-                    const int cx = floordiv(sx, Bc), cy = floordiv(sy, Bc);
-                    int k = ncells - 1;
-                    while (k >= 0 && !(cells[k].cx == cx && cells[k].cy == cy)) k--;
-                    if (k < 0) {
-                        if (ncells == 64) cells_overflow = true;
-                        else cells[ncells++] = Cell{ cx, cy, x, y, x + 1, y + 1 };
-                    } else {
-                        Cell& c = cells[k];
-                        c.x0 = std::min(c.x0, x); c.y0 = std::min(c.y0, y); c.x1 = std::max(c.x1, x + 1); c.y1 = std::max(c.y1, y + 1);
-                    }
-                }
+                if (!out) add_rect(sx, sy, x * kElePixels, y * kElePixels, (x + 1) * kElePixels, (y + 1) * kElePixels);
+                else
+                    for (int q = 0; q < 4; q++)
+                        if (!(out >> q & 1)) {
+                            const int qx0 = x * kElePixels + (q & 1) * (kElePixels / 2), qy0 = y * kElePixels + (q >> 1) * (kElePixels / 2);
+                            add_rect(sx, sy, qx0, qy0, qx0 + kElePixels / 2, qy0 + kElePixels / 2);
+                        }
             }
             table_tmp_[(size_t)y * tx + x] = ent;
         }
     }
     if (bx0 >= bx1) {                           // nothing of this frame lands on this shard, or it cannot win anywhere it lands
-        for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
+        for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
         for (Tile* t : culled) t->changed = true;
         if (owned_all) n_rendered_++;
         return true;
@@ -778,9 +798,12 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
     Win need[kMaxLevels];
     auto clampw = [](int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); };
+    // a box of level-0 pixels (multiples of 128) at level i: floor / ceil (a level of 1-pixel tiles halves a quadrant)
+    auto lo = [](int p, int i) { return p >> i; };
+    auto hi = [](int p, int i) { return (p + (1 << i) - 1) >> i; };
     for (int i = L; i >= 0; i--) {
-        const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
-        int x0 = bx0 * ts, x1 = bx1 * ts, y0 = by0 * ts, y1 = by1 * ts;
+        const int rows = crows >> i, cols = ccols >> i;
+        int x0 = lo(pbx0, i), x1 = hi(pbx1, i), y0 = lo(pby0, i), y1 = hi(pby1, i);
         if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
         if (i < L) {
             x0 = std::min(x0, 2 * need[i + 1].x0 - 2); x1 = std::max(x1, 2 * need[i + 1].x1 + 1);
@@ -872,8 +895,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         // wherever the level i+1 launch stages its halo (its region -4 / +3)
         Win C[kMaxLevels];
         for (int i = L - 1; i >= 0; i--) {
-            const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
-            int x0 = bx0 * ts, x1 = bx1 * ts, y0 = by0 * ts, y1 = by1 * ts;
+            const int rows = crows >> i, cols = ccols >> i;
+            int x0 = lo(pbx0, i), x1 = hi(pbx1, i), y0 = lo(pby0, i), y1 = hi(pby1, i);
             if (i < L - 1) {
                 x0 = std::min(x0, 2 * (C[i + 1].x0 - 4)); x1 = std::max(x1, 2 * (C[i + 1].x1 + 3));
                 y0 = std::min(y0, 2 * (C[i + 1].y0 - 4)); y1 = std::max(y1, 2 * (C[i + 1].y1 + 3));
@@ -899,8 +922,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 const Cell& ce = cells[c];
                 Win N[kMaxLevels];
                 for (int i = L; i >= 0; i--) {
-                    const int ts = kElePixels >> i, rows = crows >> i, cols = ccols >> i;
-                    int x0 = ce.x0 * ts, x1 = ce.x1 * ts, y0 = ce.y0 * ts, y1 = ce.y1 * ts;
+                    const int rows = crows >> i, cols = ccols >> i;
+                    int x0 = lo(ce.x0, i), x1 = hi(ce.x1, i), y0 = lo(ce.y0, i), y1 = hi(ce.y1, i);
                     if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
                     if (i < L) {
                         x0 = std::min(x0, 2 * N[i + 1].x0 - 2); x1 = std::max(x1, 2 * N[i + 1].x1 + 1);
@@ -910,9 +933,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                     clampw(y0, y1, rows, N[i].y0, N[i].y1);
                 }
                 for (int i = 0; i < L; i++) {
-                    const int ts = kElePixels >> i;
-                    int x0 = std::min(ce.x0 * ts, 2 * N[i + 1].x0), x1 = std::max(ce.x1 * ts, 2 * N[i + 1].x1);
-                    int y0 = std::min(ce.y0 * ts, 2 * N[i + 1].y0), y1 = std::max(ce.y1 * ts, 2 * N[i + 1].y1);
+                    int x0 = std::min(lo(ce.x0, i), 2 * N[i + 1].x0), x1 = std::max(hi(ce.x1, i), 2 * N[i + 1].x1);
+                    int y0 = std::min(lo(ce.y0, i), 2 * N[i + 1].y0), y1 = std::max(hi(ce.y1, i), 2 * N[i + 1].y1);
                     x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
                     if (x0 >= x1 || y0 >= y1) continue;
                     lv[i].push_back(R{ (x0 - C[i].x0) / 64, (y0 - C[i].y0) / BHr, (x1 - C[i].x0 + 63) / 64, (y1 - C[i].y0 + BHr - 1) / BHr });
@@ -1038,7 +1060,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
     for (Tile* t : touched) { t->fresh = false; t->changed = true; }
     for (Tile* t : culled) t->changed = true;
-    for (auto& r : raise) r.first->wlb = std::max(r.first->wlb, r.second);
+    for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
     n_rendered_++;
     return true;
 }
@@ -1060,41 +1082,57 @@ bool FusionMap::cull_frame_ok(const double M[9], int crows, int ccols) const
     return true;
 }
 
-// Bounds of the radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas
-// rectangle [x0,x1] x [y0,y1]: *wmax >= every weight the frame can have there, *wmin <= every weight it has there (0 unless the
-// rectangle maps wholly inside the frame).  The rectangle maps to a convex quadrilateral of the source plane (M is projective and W
-// keeps its sign, cull_frame_ok); the weight falls with the distance from the image centre, so the largest weight sits at the point
-// of the quadrilateral nearest to the centre and the smallest at its farthest corner.  Margins: 2 source pixels for the nearest-pixel
-// rounding (0.71) and the float arithmetic of the kernels, 1e-5 on the weight for the pyramid's own rounding.
-void FusionMap::tile_weight_bounds(const double M[9], int cols, int rows, int weight_type, double x0, double y0, double x1, double y1,
-                                   float* wmax, float* wmin)
+// The canvas lattice (64 (k - dil), 64 (m - dil)), k = 0 .. ccols / 64 + 2 dil, mapped into the source frame once per keyframe: position, distance
+// from the image centre, inside-the-frame flag.  A quadrant's dilated rectangle has its corners on it.
+void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil)
 {
-    const double cx[4] = { x0, x1, x1, x0 }, cy[4] = { y0, y0, y1, y1 };
-    double qx[4], qy[4];
-    for (int i = 0; i < 4; i++) {
-        const double W = M[6] * cx[i] + M[7] * cy[i] + M[8];
-        qx[i] = (M[0] * cx[i] + M[1] * cy[i] + M[2]) / W; qy[i] = (M[3] * cx[i] + M[4] * cy[i] + M[5]) / W;
+    lat_.dil = dil;                                             // dilation of a quadrant in lattice steps of 64 pixels
+    lat_.nx = ccols / 64 + 2 * dil + 1; lat_.ny = crows / 64 + 2 * dil + 1;
+    const size_t n = (size_t)lat_.nx * lat_.ny;
+    lat_.sx.resize(n); lat_.sy.resize(n); lat_.d.resize(n); lat_.in.resize(n);
+    lat_.xc = (double)(cols / 2); lat_.yc = (double)(rows / 2); lat_.dis_max = std::sqrt(lat_.xc * lat_.xc + lat_.yc * lat_.yc);
+    for (int m = 0; m < lat_.ny; m++) {
+        const double y = 64.0 * (m - lat_.dil), nx0 = M[1] * y + M[2], ny0 = M[4] * y + M[5], w0 = M[7] * y + M[8];
+        for (int k = 0; k < lat_.nx; k++) {
+            const double x = 64.0 * (k - lat_.dil), iw = 1.0 / (M[6] * x + w0);
+            const double px = (M[0] * x + nx0) * iw, py = (M[3] * x + ny0) * iw;
+            const size_t o = (size_t)m * lat_.nx + k;
+            lat_.sx[o] = px; lat_.sy[o] = py;
+            const double dx = px - lat_.xc, dy = py - lat_.yc;
+            lat_.d[o] = std::sqrt(dx * dx + dy * dy);
+            lat_.in[o] = px >= 1.0 && px <= cols - 2.0 && py >= 1.0 && py <= rows - 2.0;
+        }
     }
-    const double xc = (double)(cols / 2), yc = (double)(rows / 2), dis_max = std::sqrt(xc * xc + yc * yc);
-    bool inside_frame = true; double dfar = 0;
-    for (int i = 0; i < 4; i++) {
-        inside_frame = inside_frame && qx[i] >= 1.0 && qx[i] <= cols - 2.0 && qy[i] >= 1.0 && qy[i] <= rows - 2.0;
-        dfar = std::max(dfar, std::hypot(qx[i] - xc, qy[i] - yc));
-    }
+}
+
+// Bounds of the radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas
+// rectangle with lattice corners (k, m) .. (k + 2 + 2 dil, m + 2 + 2 dil) -- a quadrant of a tile dilated by 64 dil pixels: *wmax >= every weight the
+// keyframe can have there, *wmin <= every weight it has there (0 unless the rectangle maps wholly inside the frame).  The rectangle
+// maps to a convex quadrilateral of the source plane (M is projective and W keeps its sign, cull_frame_ok); the weight falls with the
+// distance from the image centre, so the largest weight sits at the point of the quadrilateral nearest to the centre and the smallest
+// at its farthest corner.  Margins: 2 source pixels for the nearest-pixel rounding (0.71) and the float arithmetic of the kernels,
+// 1e-5 on the weight for the pyramid's own rounding.
+void FusionMap::quadrant_weight_bounds(int k, int m, int weight_type, float* wmax, float* wmin) const
+{
+    const int e = 2 + 2 * lat_.dil;                             // lattice steps across the dilated quadrant
+    const size_t c[4] = { (size_t)m * lat_.nx + k, (size_t)m * lat_.nx + k + e, (size_t)(m + e) * lat_.nx + k + e, (size_t)(m + e) * lat_.nx + k };
+    const bool inside_frame = lat_.in[c[0]] && lat_.in[c[1]] && lat_.in[c[2]] && lat_.in[c[3]];
+    const double dfar = std::max(std::max(lat_.d[c[0]], lat_.d[c[1]]), std::max(lat_.d[c[2]], lat_.d[c[3]]));
     // distance from the centre to the quadrilateral: 0 inside, else to the nearest edge
-    bool pos = true, neg = true; double dnear = 1e300;
+    bool pos = true, neg = true; double dnear2 = 1e300;
     for (int i = 0; i < 4; i++) {
-        const int j = (i + 1) & 3;
-        const double ex = qx[j] - qx[i], ey = qy[j] - qy[i], px = xc - qx[i], py = yc - qy[i];
+        const size_t a = c[i], b = c[(i + 1) & 3];
+        const double ex = lat_.sx[b] - lat_.sx[a], ey = lat_.sy[b] - lat_.sy[a], px = lat_.xc - lat_.sx[a], py = lat_.yc - lat_.sy[a];
         const double cr = ex * py - ey * px;
         pos = pos && cr >= 0; neg = neg && cr <= 0;
         const double e2 = ex * ex + ey * ey;
         double t = e2 > 0 ? (px * ex + py * ey) / e2 : 0.0;
         t = t < 0 ? 0 : (t > 1 ? 1 : t);
-        dnear = std::min(dnear, std::hypot(px - t * ex, py - t * ey));
+        const double qx = px - t * ex, qy = py - t * ey;
+        dnear2 = std::min(dnear2, qx * qx + qy * qy);
     }
-    if (pos || neg) dnear = 0;
-    auto weight = [&](double d) { double w = 1.0 - d / dis_max; if (weight_type != 0) w = w > 0 ? w * w : 0.0; return w; };
+    const double dnear = (pos || neg) ? 0.0 : std::sqrt(dnear2);
+    auto weight = [&](double d) { double w = 1.0 - d / lat_.dis_max; if (weight_type != 0) w = w > 0 ? w * w : 0.0; return w; };
     const double hi = weight(std::max(0.0, dnear - 2.0)) + 1e-5;
     *wmax = (float)std::max(hi, 2e-5);                                       // inside the frame a weight is never below 1e-5
     const double lo = inside_frame ? weight(dfar + 2.0) - 1e-5 : 0.0;
@@ -1297,7 +1335,8 @@ bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
     if (!t) return false;
     HIP_OK(hipMemcpyAsync(t->base, dev_in, lay_.slot_bytes, hipMemcpyDeviceToDevice, stream_));
     HIP_OK(sync_all());
-    t->fresh = false; t->changed = true; t->wlb = -1.f;          // imported pixels: nothing known about their weights
+    t->fresh = false; t->changed = true;
+    for (float& w : t->wlb) w = -1.f;                           // imported pixels: nothing known about their weights
     return true;
 }
 

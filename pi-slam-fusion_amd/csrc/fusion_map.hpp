@@ -29,7 +29,7 @@ struct Tile {
     bool  changed = false;  // Ele::Ischanged
     // A lower bound of every weight stored in this tile, all levels (render_frame's cull): each keyframe whose canvas holds the
     // tile raises it to the smallest weight that keyframe can have anywhere in the tile's pyramid support.  <= 0: nothing known.
-    float wlb = -1.f;
+    float wlb[4] = { -1.f, -1.f, -1.f, -1.f };      // per quadrant of 128 x 128 pixels: 0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right
 };
 
 class TileStore {
@@ -122,8 +122,11 @@ public:
     bool map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y);
     // the cull of render_frame (tiles in which a keyframe cannot win the select): see there
     bool cull_frame_ok(const double M[9], int crows, int ccols) const;
-    static void tile_weight_bounds(const double M[9], int cols, int rows, int weight_type, double x0, double y0, double x1, double y1, float* wmax, float* wmin);
+    // source positions of the canvas lattice points (-64 + 64 k, -64 + 64 m) the quadrants' dilated rectangles have their corners on
+    void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil);
+    void quadrant_weight_bounds(int k, int m, int weight_type, float* wmax, float* wmin) const;
     long long culled_tiles() const { return n_culled_tiles_; }
+    long long culled_quadrants() const { return n_culled_quads_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
     int  num_levels() const { return band_num_ + 1; }
@@ -184,6 +187,8 @@ private:
     bool   valid_ = false;
     Pose   plane_{}, plane_inv_{};
     long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
+    long long n_culled_quads_ = 0;              // quadrants of rendered tiles switched off by it
+    struct { int nx = 0, ny = 0, dil = 1; double xc = 0, yc = 0, dis_max = 1; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
     double min_[3]{}, max_[3]{};

@@ -562,6 +562,18 @@ __device__ __forceinline__ WT up_h_val(WT a, WT b, WT c, bool odd, bool le, bool
     return t;
 }
 
+// A tile-table entry = slot address (256-byte aligned) | flags: bit 0 fresh (first write copies unconditionally), bits 1..4 the
+// quadrants (128 x 128 level-0 pixels each: 1 = right half, 2 = lower half) in which this keyframe cannot win the max-weight select at
+// any level (the cull of FusionMap::render_frame): pixels there are not looked at -- they may have been computed from input that was
+// never produced.  Entries written without the cull carry no such bits.
+constexpr uint64_t kEntFlags = 0xff;
+__device__ __forceinline__ bool quadrant_culled(uint64_t ent, int x, int y, int ts)
+{
+    const int hs = ts >> 1;                                   // a level of 1-pixel tiles has no quadrants
+    const int q = ((y & (ts - 1)) >= hs ? 2 : 0) | ((x & (ts - 1)) >= hs ? 1 : 0);
+    return hs != 0 && ((ent >> (1 + q)) & 1) != 0;
+}
+
 // max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
 template <bool F32, typename TablePtr>
 __device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, int level, TablePtr table, int tiles_x,
@@ -570,8 +582,8 @@ __device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, i
     using T = typename Pix<F32>::T;
     const int sh = 8 - level, ts = kElePixels >> level;
     const uint64_t ent = table[(y >> sh) * tiles_x + (x >> sh)];
-    if (!ent) return;
-    const uint64_t slot = ent & ~(uint64_t)1;
+    if (!ent || quadrant_culled(ent, x, y, ts)) return;
+    const uint64_t slot = ent & ~kEntFlags;
     const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
     float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + w_off) + loc;
     if (!(ent & 1) && !(sw >= *dw)) return;
@@ -906,6 +918,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         const int ti = (dy0 >> sh) * g.tiles_x + (dx0 >> sh);
         if (tab0) ent = ((const uint64_t PF_GLOBAL*)tab0)[ti];
         else ent = table[ti];
+        if (quadrant_culled(ent, dx0, dy0, ts)) ent = 0;
     }
 
     // ---- A
@@ -1107,7 +1120,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
 
     // stored weights of the quad: in flight during stage B
     float dwv[2][2] = { { -1.f, -1.f }, { -1.f, -1.f } };           // fresh tile: every weight (>= 0) wins
-    const uint64_t slot = ent & ~(uint64_t)1;
+    const uint64_t slot = ent & ~kEntFlags;
     const int loc0 = (dy0 & (ts - 1)) * ts + (dx0 & (ts - 1));
     if (ent && !(ent & 1)) {
         const float PF_GLOBAL* wp = (const float PF_GLOBAL*)(slot + lay.w_off) + loc0;
