@@ -700,7 +700,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // Cull (round 4): a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- its
     // table entry stays 0, exactly as if another shard owned it, and the need rectangles below shrink the grid to what the
     // remaining tiles depend on.  Nothing changes in what is stored: `if (srcW >= dstW)` (.cpp:521, :542) is false at every pixel
-    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (quadrant_weight_bounds):
+    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (quadrant_out):
     //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the tile dilated by the pyramid's
     //                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
     //   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
@@ -716,6 +716,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // pixels (kernels.hip, quadrant_culled), which may have been computed from input nobody produced.
     struct Raise { Tile* t; int q; float w; };
     std::vector<Raise> raise;                                    // (quadrant, wmin of this keyframe): applied once the frame is in
+    if (cull) raise.reserve((size_t)tx * ty * 4);
     std::vector<Tile*> culled;
     if (cull) cull_lattice(Minv, crows, ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
     bool culled_any = false;
@@ -757,10 +758,9 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 unsigned out = 0;                                  // quadrants in which this keyframe cannot win
                 if (cull) {
                     for (int q = 0; q < 4; q++) {
-                        float wmax, wmin;
-                        quadrant_weight_bounds(4 * x + 2 * (q & 1), 4 * y + 2 * (q >> 1), opt_.weight_type, &wmax, &wmin);
+                        float wmin;
+                        if (quadrant_out(4 * x + 2 * (q & 1), 4 * y + 2 * (q >> 1), opt_.weight_type, t->wlb[q], !t->fresh, &wmin)) out |= 1u << q;
                         if (wmin > t->wlb[q]) raise.push_back(Raise{ t, q, wmin });
-                        if (!t->fresh && wmax < t->wlb[q]) out |= 1u << q;
                     }
                     if (out == 15u) {
                         // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
@@ -1082,61 +1082,79 @@ bool FusionMap::cull_frame_ok(const double M[9], int crows, int ccols) const
     return true;
 }
 
-// The canvas lattice (64 (k - dil), 64 (m - dil)), k = 0 .. ccols / 64 + 2 dil, mapped into the source frame once per keyframe: position, distance
-// from the image centre, inside-the-frame flag.  A quadrant's dilated rectangle has its corners on it.
+// The canvas lattice (64 (k - dil), 64 (m - dil)), k = 0 .. ccols / 64 + 2 dil, mapped into the source frame: position, squared distance
+// from the image centre, inside-the-frame flag.  A quadrant's dilated rectangle has its corners on it.  Points are mapped on first use
+// (a shard asks for an eighth of them); one division per point, no square root.
 void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil)
 {
     lat_.dil = dil;                                             // dilation of a quadrant in lattice steps of 64 pixels
     lat_.nx = ccols / 64 + 2 * dil + 1; lat_.ny = crows / 64 + 2 * dil + 1;
     const size_t n = (size_t)lat_.nx * lat_.ny;
-    lat_.sx.resize(n); lat_.sy.resize(n); lat_.d.resize(n); lat_.in.resize(n);
+    lat_.sx.resize(n); lat_.sy.resize(n); lat_.d.resize(n); lat_.in.assign(n, 2);          // 2: not mapped yet
     lat_.xc = (double)(cols / 2); lat_.yc = (double)(rows / 2); lat_.dis_max = std::sqrt(lat_.xc * lat_.xc + lat_.yc * lat_.yc);
-    for (int m = 0; m < lat_.ny; m++) {
-        const double y = 64.0 * (m - lat_.dil), nx0 = M[1] * y + M[2], ny0 = M[4] * y + M[5], w0 = M[7] * y + M[8];
-        for (int k = 0; k < lat_.nx; k++) {
-            const double x = 64.0 * (k - lat_.dil), iw = 1.0 / (M[6] * x + w0);
-            const double px = (M[0] * x + nx0) * iw, py = (M[3] * x + ny0) * iw;
-            const size_t o = (size_t)m * lat_.nx + k;
-            lat_.sx[o] = px; lat_.sy[o] = py;
-            const double dx = px - lat_.xc, dy = py - lat_.yc;
-            lat_.d[o] = std::sqrt(dx * dx + dy * dy);
-            lat_.in[o] = px >= 1.0 && px <= cols - 2.0 && py >= 1.0 && py <= rows - 2.0;
-        }
-    }
+    lat_.inv_dis_max = 1.0 / lat_.dis_max;
+    lat_.cols = cols; lat_.rows = rows;
+    for (int i = 0; i < 9; i++) lat_.M[i] = M[i];
 }
 
-// Bounds of the radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas
-// rectangle with lattice corners (k, m) .. (k + 2 + 2 dil, m + 2 + 2 dil) -- a quadrant of a tile dilated by 64 dil pixels: *wmax >= every weight the
-// keyframe can have there, *wmin <= every weight it has there (0 unless the rectangle maps wholly inside the frame).  The rectangle
-// maps to a convex quadrilateral of the source plane (M is projective and W keeps its sign, cull_frame_ok); the weight falls with the
-// distance from the image centre, so the largest weight sits at the point of the quadrilateral nearest to the centre and the smallest
-// at its farthest corner.  Margins: 2 source pixels for the nearest-pixel rounding (0.71) and the float arithmetic of the kernels,
-// 1e-5 on the weight for the pyramid's own rounding.
-void FusionMap::quadrant_weight_bounds(int k, int m, int weight_type, float* wmax, float* wmin) const
+inline size_t FusionMap::lattice_point(int k, int m)
+{
+    const size_t o = (size_t)m * lat_.nx + k;
+    if (lat_.in[o] == 2) {
+        const double* M = lat_.M;
+        const double x = 64.0 * (k - lat_.dil), y = 64.0 * (m - lat_.dil), iw = 1.0 / (M[6] * x + M[7] * y + M[8]);
+        const double px = (M[0] * x + M[1] * y + M[2]) * iw, py = (M[3] * x + M[4] * y + M[5]) * iw;
+        lat_.sx[o] = px; lat_.sy[o] = py;
+        const double dx = px - lat_.xc, dy = py - lat_.yc;
+        lat_.d[o] = dx * dx + dy * dy;
+        lat_.in[o] = px >= 1.0 && px <= lat_.cols - 2.0 && py >= 1.0 && py <= lat_.rows - 2.0;
+    }
+    return o;
+}
+
+// The radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas rectangle with
+// lattice corners (k, m) .. (k + 2 + 2 dil, m + 2 + 2 dil) -- a quadrant of a tile dilated by 64 dil pixels -- against `wlb`, the lower
+// bound of what the quadrant stores:
+//   returns true when every weight the keyframe can have there is below wlb (the quadrant is out);
+//   *wmin <= every weight it has there (0 unless the rectangle maps wholly inside the frame).
+// The rectangle maps to a convex quadrilateral Q of the source plane (M is projective and W keeps its sign, cull_frame_ok); the weight
+// falls with the distance from the image centre c, so the largest weight sits at the point of Q nearest to c and the smallest at its
+// farthest corner.  "Largest weight < wlb" <=> dist(c, Q) > T, T the distance at which the weight -- with the margins below -- reaches
+// wlb; decided from the corners alone when one of them lies within T (most quadrants that stay in), by the exact point-to-quadrilateral
+// distance otherwise.  Margins: 2 source pixels for the nearest-pixel rounding (0.71) and the float arithmetic of the kernels, 1e-5 on
+// the weight for the pyramid's own rounding.
+bool FusionMap::quadrant_out(int k, int m, int weight_type, float wlb, bool want_out, float* wmin)
 {
     const int e = 2 + 2 * lat_.dil;                             // lattice steps across the dilated quadrant
-    const size_t c[4] = { (size_t)m * lat_.nx + k, (size_t)m * lat_.nx + k + e, (size_t)(m + e) * lat_.nx + k + e, (size_t)(m + e) * lat_.nx + k };
-    const bool inside_frame = lat_.in[c[0]] && lat_.in[c[1]] && lat_.in[c[2]] && lat_.in[c[3]];
-    const double dfar = std::max(std::max(lat_.d[c[0]], lat_.d[c[1]]), std::max(lat_.d[c[2]], lat_.d[c[3]]));
-    // distance from the centre to the quadrilateral: 0 inside, else to the nearest edge
+    const size_t c[4] = { lattice_point(k, m), lattice_point(k + e, m), lattice_point(k + e, m + e), lattice_point(k, m + e) };
+    const double d2[4] = { lat_.d[c[0]], lat_.d[c[1]], lat_.d[c[2]], lat_.d[c[3]] };
+    *wmin = 0.f;
+    if (lat_.in[c[0]] == 1 && lat_.in[c[1]] == 1 && lat_.in[c[2]] == 1 && lat_.in[c[3]] == 1) {
+        const double dfar = std::sqrt(std::max(std::max(d2[0], d2[1]), std::max(d2[2], d2[3]))) + 2.0;
+        double w = 1.0 - dfar * lat_.inv_dis_max;
+        if (weight_type != 0) w = w > 0 ? w * w : 0.0;
+        w -= 1e-5;
+        if (w > 2e-5) *wmin = (float)w;
+    }
+    if (!want_out || !(wlb > 2e-5f)) return false;                // nothing known about the stored weights (or a fresh tile): in
+    // T: weight(T - 2) + 1e-5 == wlb
+    double g = (double)wlb - 1e-5;
+    if (weight_type != 0) g = std::sqrt(g);
+    const double T = 2.0 + lat_.dis_max * (1.0 - g), T2 = T * T;
+    if (d2[0] <= T2 || d2[1] <= T2 || d2[2] <= T2 || d2[3] <= T2) return false;      // a corner within T
     bool pos = true, neg = true; double dnear2 = 1e300;
     for (int i = 0; i < 4; i++) {
         const size_t a = c[i], b = c[(i + 1) & 3];
         const double ex = lat_.sx[b] - lat_.sx[a], ey = lat_.sy[b] - lat_.sy[a], px = lat_.xc - lat_.sx[a], py = lat_.yc - lat_.sy[a];
         const double cr = ex * py - ey * px;
         pos = pos && cr >= 0; neg = neg && cr <= 0;
-        const double e2 = ex * ex + ey * ey;
-        double t = e2 > 0 ? (px * ex + py * ey) / e2 : 0.0;
-        t = t < 0 ? 0 : (t > 1 ? 1 : t);
-        const double qx = px - t * ex, qy = py - t * ey;
-        dnear2 = std::min(dnear2, qx * qx + qy * qy);
+        const double e2 = ex * ex + ey * ey, dot = px * ex + py * ey;
+        // squared distance from c to the segment: the end points are the corners (known to lie beyond T), the foot of the perpendicular counts
+        // only when it falls inside the segment
+        if (dot > 0 && dot < e2) dnear2 = std::min(dnear2, cr * cr / e2);
     }
-    const double dnear = (pos || neg) ? 0.0 : std::sqrt(dnear2);
-    auto weight = [&](double d) { double w = 1.0 - d / lat_.dis_max; if (weight_type != 0) w = w > 0 ? w * w : 0.0; return w; };
-    const double hi = weight(std::max(0.0, dnear - 2.0)) + 1e-5;
-    *wmax = (float)std::max(hi, 2e-5);                                       // inside the frame a weight is never below 1e-5
-    const double lo = inside_frame ? weight(dfar + 2.0) - 1e-5 : 0.0;
-    *wmin = lo > 2e-5 ? (float)lo : 0.f;
+    if (pos || neg) return false;                               // the centre lies inside Q: the keyframe's best weights are here
+    return dnear2 > T2;
 }
 
 // Retirement without an event per frame (see the header): count the submission, drop a marker now and then.

@@ -124,7 +124,8 @@ public:
     bool cull_frame_ok(const double M[9], int crows, int ccols) const;
     // source positions of the canvas lattice points (-64 + 64 k, -64 + 64 m) the quadrants' dilated rectangles have their corners on
     void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil);
-    void quadrant_weight_bounds(int k, int m, int weight_type, float* wmax, float* wmin) const;
+    size_t lattice_point(int k, int m);
+    bool quadrant_out(int k, int m, int weight_type, float wlb, bool want_out, float* wmin);
     long long culled_tiles() const { return n_culled_tiles_; }
     long long culled_quadrants() const { return n_culled_quads_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
@@ -188,7 +189,7 @@ private:
     Pose   plane_{}, plane_inv_{};
     long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
     long long n_culled_quads_ = 0;              // quadrants of rendered tiles switched off by it
-    struct { int nx = 0, ny = 0, dil = 1; double xc = 0, yc = 0, dis_max = 1; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
+    struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
     double min_[3]{}, max_[3]{};
