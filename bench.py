@@ -86,7 +86,7 @@ def kernels_sha():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "pi-slam-fusion_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp", ".inc")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
