@@ -331,10 +331,13 @@ def main():
     ap.add_argument("--no-strong-probe", action="store_true", help="N > 1, --shard weak: skip the tile-sharded sub-measurement")
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 8)")
+    ap.add_argument("--no-cull", action="store_true", help="render every tile of every keyframe's canvas (PF_CULL=0): the full_render_no_cull sub-record")
     ap.add_argument("--no-pre", action="store_true",
                     help="do not fly the 20 - W keyframes of the sortie's first line before the warm-up: a short run then times that "
                          "first line (every tile new, nothing culled), as round 2's driver record did")
     args = ap.parse_args()
+    if args.no_cull:
+        os.environ["PF_CULL"] = "0"          # read when a map is created
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -528,6 +531,20 @@ def main():
 
     # the other pyramid type in the same run (the reference's default is CV_16SC3; north_star's parity bar is on fp32)
     if not args.no_cpu and N == 1:
+        # the same run with the cull off: every tile of every keyframe's canvas rendered, as the reference does (same mosaic; what the
+        # headline gains by leaving out quadrants in which the keyframe cannot win the select).  In a child process of its own: the
+        # third timed run inside one process submits slowly on this stack (measured: 2400-4600 keyframes/s for runs that take their usual
+        # 150 us per launch) -- an artefact of the bench process, not of the engine; a fresh process shows the rate a user gets.
+        def full_render():
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-cull", "--steps", str(K), "--warmup", str(W), "--scale", str(args.scale)]
+            if args.int16:
+                cmd.append("--int16")
+            if args.no_pre:
+                cmd.append("--no-pre")
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            return {"value": j["value"], "unit": "keyframes/s", "dtype": j["dtype"], "ms_per_step": j["ms_per_step"],
+                    "culled_tiles": j["config"]["culled_tiles_rank0"], "roofline": j["roofline"]}
         def other_dtype():
             m2, _ = make_map(1 - force_float)
             assert m2.prepare(wl.IDENTITY_PLANE, CAM, prep)
@@ -541,6 +558,8 @@ def main():
             m2.close()
             return rec
         out["int16" if force_float else "f32"] = guarded(other_dtype)
+        out["full_render_no_cull"] = guarded(full_render)
+
 
     if rank == 0 and not args.no_cpu:
         hostf = guarded(lambda: [f.cpu().numpy() for f in frames[:2]])

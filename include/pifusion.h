@@ -267,6 +267,9 @@ int     pf_timer_reset(pf_map* m);
 /* Tiles left out of launches so far because the keyframe fed could not win the max-weight select anywhere in them (the cull of
  * render_frame: bounds from the geometry alone; results are those of the full render, PF_CULL=0 switches it off). Diagnostics. */
 long long pf_debug_culled_tiles(pf_map* m);
+/* The cull on (default, unless PF_CULL=0 is in the environment) or off: off renders every tile of every keyframe's canvas, as the
+ * reference does; the mosaic is the same either way.  For measurements (bench.py reports both rates). */
+void    pf_set_cull(pf_map* m, int on);
 /* Launches of the pipelined level kernel by form since the library was loaded: [0] block form with the computed weight (default),
  * [1] block form gathering the weight plane, [2] LDS-staged source patch, [3] rolling strips, [4] 64x64 blocks, [5] 64x28 blocks,
  * [6] stamped instantiation, [7] launches whose tile table travelled in the kernel arguments.  Diagnostics (variant tests). */

@@ -125,6 +125,7 @@ def lib():
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
     L.pf_debug_culled_tiles.argtypes = [vp]; L.pf_debug_culled_tiles.restype = C.c_longlong
+    L.pf_set_cull.argtypes = [vp, C.c_int]; L.pf_set_cull.restype = None
     L.pf_render_stats.argtypes = [vp, dp]
     L.pf_timer_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp, dp]
     L.pf_timer_reset.argtypes = [vp]
@@ -400,6 +401,10 @@ class Map2D:
 
     def timer_reset(self):
         lib().pf_timer_reset(self._h)
+
+    def set_cull(self, on):
+        """the cull of render_frame on / off (off: every tile of every canvas rendered, as the reference does; same mosaic)"""
+        lib().pf_set_cull(self._h, 1 if on else 0)
 
     def culled_tiles(self):
         """tiles left out of launches because the keyframe could not win the select anywhere in them (diagnostics)"""

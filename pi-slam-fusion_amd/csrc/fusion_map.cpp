@@ -707,9 +707,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     //                 dilated tile, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
     //                 then S_i > W_i^f.  Tile::wlb[quadrant] = max over f of wmin_f.
     // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
-    static const bool cull_env = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
     double Minv[9];
-    const bool cull = cull_env && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
+    const bool cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
     // The unit of the cull is a QUADRANT of a tile (128 x 128 pixels), dilated by the pyramid's support radius 2^(L+1) - 2 pixels
     // rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose four quadrants are all out is left out
     // of the launch; otherwise the quadrants that are out travel as flag bits of its table entry and the kernels do not look at their

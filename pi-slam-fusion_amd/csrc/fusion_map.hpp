@@ -6,6 +6,7 @@
 #include "kernels.hpp"
 #include <hip/hip_runtime.h>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
 #include <string>
@@ -127,6 +128,7 @@ public:
     size_t lattice_point(int k, int m);
     bool quadrant_out(int k, int m, int weight_type, float wlb, bool want_out, float* wmin);
     long long culled_tiles() const { return n_culled_tiles_; }
+    void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); cull_on_ = on; }       // default: on unless PF_CULL=0
     long long culled_quadrants() const { return n_culled_quads_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
@@ -187,6 +189,7 @@ private:
     std::mutex mu_;
     bool   valid_ = false;
     Pose   plane_{}, plane_inv_{};
+    bool cull_on_ = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
     long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
     long long n_culled_quads_ = 0;              // quadrants of rendered tiles switched off by it
     struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
