@@ -286,11 +286,11 @@ def timed_run(m, run, W, K, event_every, barrier):
     return t1 - t0, dom, p, prof
 
 
-def roofline_record(dom, p, dtype_key, event_every):
+def roofline_record(dom, p, dtype_key, event_every, pmc_ok=True):
     ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
     launches = max(p["launches"], 1)
     us = p["ms"] / launches * 1e3
-    pmc = pmc_record(dtype_key, dom)
+    pmc = pmc_record(dtype_key, dom) if pmc_ok else None      # the committed PMC passes are cfg-A's (Map2D.Scale = 1)
     # "bound" names the roofline `achieved`/`peak` are priced against (HBM bytes: north_star asks for % of the HBM roofline);
     # "limiter" below says what the counters show the launch is actually held by
     rec = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -494,7 +494,7 @@ def main():
                        # tiles of the timed keyframes' canvases left out of the launches because the keyframe cannot win the max-weight
                        # select anywhere in them (geometric bound, results identical to the full render; PF_CULL=0 renders them all)
                        "culled_tiles_rank0": m.culled_tiles()},
-            "roofline": guarded(roofline_record, dom, p, dkey, ev_every),
+            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0),
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
         }
@@ -554,7 +554,7 @@ def main():
             dt2, dom2, p2, _ = timed_run(m2, make_run(m2), W, K, ev_every, barrier)
             k2 = "f32" if not force_float else "int16"
             rec = {"value": round(K / dt2, 3), "unit": "keyframes/s", "dtype": k2, "ms_per_step": round(dt2 / K * 1e3, 4),
-                   "roofline": roofline_record(dom2, p2, k2, ev_every)}
+                   "roofline": roofline_record(dom2, p2, k2, ev_every, args.scale == 1.0)}
             m2.close()
             return rec
         out["int16" if force_float else "f32"] = guarded(other_dtype)
