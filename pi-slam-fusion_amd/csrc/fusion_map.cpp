@@ -968,6 +968,23 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 for (uint8_t v : block_bits_) blocks_run0 += v;
             }
             px_level0_ += blocks_run0 * 64 * BHr;
+            static const bool exact_stat = std::getenv("PF_CULL_EXACT_STAT") != nullptr;
+            if (exact_stat) {       // diagnostics: level-0 blocks within the pyramid's reach (94 px for five bands) of a quadrant that is rendered
+                const int R0 = 94, nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+                long cnt = 0;
+                for (int gy = 0; gy < nby; gy++)
+                    for (int gx = 0; gx < nbx; gx++) {
+                        const int x0 = C[0].x0 + gx * 64 - R0, x1 = C[0].x0 + gx * 64 + 63 + R0, y0 = C[0].y0 + gy * BHr - R0, y1 = C[0].y0 + gy * BHr + BHr - 1 + R0;
+                        bool need = false;
+                        for (int qy = std::max(y0, 0) >> 7; qy <= (std::min(y1, crows - 1) >> 7) && !need; qy++)
+                            for (int qx = std::max(x0, 0) >> 7; qx <= (std::min(x1, ccols - 1) >> 7) && !need; qx++) {
+                                const uint64_t e = table_tmp_[(size_t)(qy >> 1) * tx + (qx >> 1)];
+                                need = e != 0 && !((e >> (1 + (qy & 1) * 2 + (qx & 1))) & 1);
+                            }
+                        cnt += need;
+                    }
+                px_level0_exact_ += (double)cnt * 64 * BHr;
+            }
         } else
             px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
         if (opt_.fused == 1) {

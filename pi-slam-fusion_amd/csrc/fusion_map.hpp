@@ -130,6 +130,7 @@ public:
     long long culled_tiles() const { return n_culled_tiles_; }
     void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); cull_on_ = on; }       // default: on unless PF_CULL=0
     long long culled_quadrants() const { return n_culled_quads_; }
+    double level0_exact_px() const { return px_level0_exact_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
     int  num_levels() const { return band_num_ + 1; }
@@ -268,6 +269,7 @@ private:
     SectionRec sections_[T_COUNT];
     std::mutex timer_mu_;
     long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0, n_with_pixels_ = 0;
+    double px_level0_exact_ = 0;                    // PF_CULL_EXACT_STAT (diagnostics)
     double px_level0_ = 0, px_owned_ = 0;           // level-0 pixels computed (with halo) / tile pixels owned, over the frames rendered
 };
 

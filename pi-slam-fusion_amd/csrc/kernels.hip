@@ -1416,7 +1416,11 @@ struct LevelJob {
 };
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
 // in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
+// need_r0 (job 0, tile table in the arguments): instead of the need rectangles, a level-0 block decides for itself whether anything
+// rendered depends on it -- whether a quadrant that is rendered (entry != 0, quadrant flag clear) lies within need_r0 = 3 * 2^L - 2
+// pixels of it, the reach of the pyramid (`need` recursion of FusionMap::render_frame: pyrDown reads [2p-2, 2p+2], pyrUp +-1).
+// Exact at quadrant granularity, where eight bounding boxes are not (profiles/r04_ab.md).
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
@@ -1452,6 +1456,19 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
         tab0 = (const uint64_t*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LevelBatch, tab0));
         if (b == 0) for (int i = threadIdx.x; i < batch.tab0_n; i += LNT) const_cast<uint64_t*>(J.table)[i] = tab0[i];
     }
+    if (j == 0 && tab0 && batch.need_r0 && J.nrect) {
+        // job 0: is a rendered quadrant within the pyramid's reach of this block?
+        const int bx = bb % J.g.nbx, by = bb / J.g.nbx, r0 = batch.need_r0;
+        int x0 = J.g.cx0 + bx * LBW - r0, x1 = J.g.cx0 + bx * LBW + LBW - 1 + r0, y0 = J.g.cy0 + by * LBH - r0, y1 = J.g.cy0 + by * LBH + LBH - 1 + r0;
+        x0 = x0 > 0 ? x0 : 0; y0 = y0 > 0 ? y0 : 0; x1 = x1 < J.g.cols - 1 ? x1 : J.g.cols - 1; y1 = y1 < J.g.rows - 1 ? y1 : J.g.rows - 1;
+        bool hit = false;
+        for (int qy = y0 >> 7; qy <= (y1 >> 7); qy++)
+            for (int qx = x0 >> 7; qx <= (x1 >> 7); qx++) {
+                const uint64_t e = tab0[(qy >> 1) * J.g.tiles_x + (qx >> 1)];
+                hit = hit || (e != 0 && !((e >> (1 + (qy & 1) * 2 + (qx & 1))) & 1));
+            }
+        if (!hit) return;
+    } else
     if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
         const int bx = bb % J.g.nbx, by = bb / J.g.nbx;
         bool hit = false;
@@ -1695,6 +1712,9 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     batch.sequential = upper_first ? 2 : !interleave;
     static const int rect_runs = getenv("PF_RECT_ORDER") ? atoi(getenv("PF_RECT_ORDER")) : 0;      // 1: XCD runs even with rectangles; 2: round robin always (A/B)
     batch.rect_runs = rect_runs;
+    static const bool no_need_r0 = getenv("PF_NO_NEED_R0") != nullptr;                              // A/B: the need rectangles for job 0 too
+    if (!no_need_r0 && batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0 && batch.tab0_n && batch.job[0].nrect && BH == 32)
+        batch.need_r0 = 3 * (1 << (lay.nlev - 1)) - 2;
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {

@@ -11,4 +11,7 @@ m.sync(); a = m.render_stats()
 for k in range(20, 220): m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k])
 m.sync(); b = m.render_stats()
 n = 200
+import ctypes as C
+L = pf.lib(); L.pf_debug_level0_exact_px.restype = C.c_double; L.pf_debug_level0_exact_px.argtypes = [C.c_void_p]
+print("exact rule (PF_CULL_EXACT_STAT=1): %.2f M per keyframe incl. the first 20" % (L.pf_debug_level0_exact_px(m._h) / 220 / 1e6))
 print("per keyframe: level-0 px run %.2f M, tile px not culled %.2f M (canvas 14.48 M); frames with pixels %d" % ((b["level0_px"] - a["level0_px"]) / n / 1e6, (b["owned_px"] - a["owned_px"]) / n / 1e6, b["frames_with_pixels"] - a["frames_with_pixels"]))
