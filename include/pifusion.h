@@ -267,6 +267,11 @@ int     pf_timer_reset(pf_map* m);
 /* Tiles left out of launches so far because the keyframe fed could not win the max-weight select anywhere in them (the cull of
  * render_frame: bounds from the geometry alone; results are those of the full render, PF_CULL=0 switches it off). Diagnostics. */
 long long pf_debug_culled_tiles(pf_map* m);
+/* ... and the 64 x 64 cells (16 per tile) switched off inside tiles that were rendered.  Diagnostics. */
+long long pf_debug_culled_cells(pf_map* m);
+/* With PF_CULL_EXACT_STAT=1 in the environment: level-0 pixels of the blocks within the pyramid's reach of a rendered cell, summed
+ * over the keyframes fed (what the in-kernel need test lets run; tools/cull_stats.py).  0 otherwise.  Diagnostics. */
+double  pf_debug_level0_exact_px(pf_map* m);
 /* The cull on (default, unless PF_CULL=0 is in the environment) or off: off renders every tile of every keyframe's canvas, as the
  * reference does; the mosaic is the same either way.  For measurements (bench.py reports both rates). */
 void    pf_set_cull(pf_map* m, int on);

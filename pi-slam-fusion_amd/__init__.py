@@ -126,6 +126,8 @@ def lib():
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
     L.pf_debug_culled_tiles.argtypes = [vp]; L.pf_debug_culled_tiles.restype = C.c_longlong
     L.pf_set_cull.argtypes = [vp, C.c_int]; L.pf_set_cull.restype = None
+    L.pf_debug_culled_cells.argtypes = [vp]; L.pf_debug_culled_cells.restype = C.c_longlong
+    L.pf_debug_level0_exact_px.argtypes = [vp]; L.pf_debug_level0_exact_px.restype = C.c_double
     L.pf_render_stats.argtypes = [vp, dp]
     L.pf_timer_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_longlong), dp, dp, dp]
     L.pf_timer_reset.argtypes = [vp]
@@ -409,6 +411,10 @@ class Map2D:
     def culled_tiles(self):
         """tiles left out of launches because the keyframe could not win the select anywhere in them (diagnostics)"""
         return int(lib().pf_debug_culled_tiles(self._h))
+
+    def culled_cells(self):
+        """64 x 64 cells switched off inside tiles that were rendered (diagnostics)"""
+        return int(lib().pf_debug_culled_cells(self._h))
 
     def stats(self):
         a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()

@@ -61,7 +61,7 @@ int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { retur
 int pf_debug_phase_stamps(unsigned long long* out, int cap_blocks) { return pf::read_phase_stamps(out, cap_blocks); }
 void pf_debug_form_counts(long long out[8]) { if (out) pf::read_form_counts(out); }
 void pf_set_cull(pf_map* m, int on) { if (m) m->impl.set_cull(on != 0); }
-long long pf_debug_culled_quadrants(pf_map* m) { return m ? m->impl.culled_quadrants() : 0; }
+long long pf_debug_culled_cells(pf_map* m) { return m ? m->impl.culled_cells() : 0; }
 double pf_debug_level0_exact_px(pf_map* m) { return m ? m->impl.level0_exact_px() : 0; }
 long long pf_debug_culled_tiles(pf_map* m) { return m ? m->impl.culled_tiles() : 0; }
 int pf_debug_select_counts(unsigned long long* out, int reset) { return out ? pf::read_select_counts(out, reset) : 0; }

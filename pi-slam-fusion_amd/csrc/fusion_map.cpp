@@ -709,13 +709,14 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
     double Minv[9];
     const bool cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
-    // The unit of the cull is a QUADRANT of a tile (128 x 128 pixels), dilated by the pyramid's support radius 2^(L+1) - 2 pixels
-    // rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose four quadrants are all out is left out
-    // of the launch; otherwise the quadrants that are out travel as flag bits of its table entry and the kernels do not look at their
-    // pixels (kernels.hip, quadrant_culled), which may have been computed from input nobody produced.
+    // The unit of the cull is a CELL of a tile (64 x 64 pixels, 16 per tile; PF_CULL_SUB=2: a quadrant), dilated by the pyramid's support
+    // radius 2^(L+1) - 2 pixels rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose cells are
+    // all out is left out of the launch; otherwise the cells that are out travel as flag bits of its table entry and the kernels do not
+    // look at their pixels (kernels.hip, cell_culled), which may have been computed from input nobody produced.
     struct Raise { Tile* t; int q; float w; };
-    std::vector<Raise> raise;                                    // (quadrant, wmin of this keyframe): applied once the frame is in
-    if (cull) raise.reserve((size_t)tx * ty * 4);
+    std::vector<Raise> raise;                                    // (cell, wmin of this keyframe): applied once the frame is in
+    const int S = cull_sub_, span = 4 / S;                       // cells per tile edge; lattice steps per cell
+    if (cull) raise.reserve((size_t)tx * ty * S * S);
     std::vector<Tile*> culled;
     if (cull) cull_lattice(Minv, crows, ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
     bool culled_any = false;
@@ -754,32 +755,35 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 Tile* t = store_.get_or_create(sx, sy);
                 if (!t) return false;
                 owned_all++;
-                unsigned out = 0;                                  // quadrants in which this keyframe cannot win
+                unsigned out = 0;                                  // 64 x 64 cells in which this keyframe cannot win (bit 4 * row + column)
                 if (cull) {
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < S * S; q++) {
+                        const int qx = q % S, qy = q / S;
                         float wmin;
-                        if (quadrant_out(4 * x + 2 * (q & 1), 4 * y + 2 * (q >> 1), opt_.weight_type, t->wlb[q], !t->fresh, &wmin)) out |= 1u << q;
+                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, t->wlb[q], !t->fresh, &wmin))
+                            out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
                         if (wmin > t->wlb[q]) raise.push_back(Raise{ t, q, wmin });
                     }
-                    if (out == 15u) {
+                    if (out == 0xffffu) {
                         // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
                         // (.cpp:553), and draw() re-blends it with whatever its neighbours have become
                         culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; culled.push_back(t);
                         continue;
                     }
-                    if (out) { culled_any = true; n_culled_quads_ += __builtin_popcount(out); }
+                    if (out) { culled_any = true; n_culled_cells_ += __builtin_popcount(out); }
                 }
-                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u) | (uint64_t)(out << 1);
+                ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u) | ((uint64_t)out << 48);
                 touched.push_back(t);
                 owned++;
                 bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
                 if (!out) add_rect(sx, sy, x * kElePixels, y * kElePixels, (x + 1) * kElePixels, (y + 1) * kElePixels);
                 else
-                    for (int q = 0; q < 4; q++)
-                        if (!(out >> q & 1)) {
-                            const int qx0 = x * kElePixels + (q & 1) * (kElePixels / 2), qy0 = y * kElePixels + (q >> 1) * (kElePixels / 2);
-                            add_rect(sx, sy, qx0, qy0, qx0 + kElePixels / 2, qy0 + kElePixels / 2);
-                        }
+                    for (int r = 0; r < 4; r++) {                  // the rendered cells, row by row as runs
+                        const unsigned in = ~(out >> (4 * r)) & 15u;
+                        if (!in) continue;
+                        const int c0 = __builtin_ctz(in), c1 = 32 - __builtin_clz(in);
+                        add_rect(sx, sy, x * kElePixels + 64 * c0, y * kElePixels + 64 * r, x * kElePixels + 64 * c1, y * kElePixels + 64 * r + 64);
+                    }
             }
             table_tmp_[(size_t)y * tx + x] = ent;
         }
@@ -797,7 +801,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
     Win need[kMaxLevels];
     auto clampw = [](int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); };
-    // a box of level-0 pixels (multiples of 128) at level i: floor / ceil (a level of 1-pixel tiles halves a quadrant)
+    // a box of level-0 pixels (multiples of 64) at level i: floor / ceil (at the top levels a cell is less than a pixel)
     auto lo = [](int p, int i) { return p >> i; };
     auto hi = [](int p, int i) { return (p + (1 << i) - 1) >> i; };
     for (int i = L; i >= 0; i--) {
@@ -895,7 +899,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         Win C[kMaxLevels];
         for (int i = L - 1; i >= 0; i--) {
             const int rows = crows >> i, cols = ccols >> i;
-            int x0 = lo(pbx0, i), x1 = hi(pbx1, i), y0 = lo(pby0, i), y1 = hi(pby1, i);
+            // the origin stays even (a block's quads and its part of level i+1 start on even pixels): a box of 64-pixel cells is odd at level 6
+            int x0 = lo(pbx0, i) & ~1, x1 = hi(pbx1, i), y0 = lo(pby0, i) & ~1, y1 = hi(pby1, i);
             if (i < L - 1) {
                 x0 = std::min(x0, 2 * (C[i + 1].x0 - 4)); x1 = std::max(x1, 2 * (C[i + 1].x1 + 3));
                 y0 = std::min(y0, 2 * (C[i + 1].y0 - 4)); y1 = std::max(y1, 2 * (C[i + 1].y1 + 3));
@@ -969,17 +974,17 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             }
             px_level0_ += blocks_run0 * 64 * BHr;
             static const bool exact_stat = std::getenv("PF_CULL_EXACT_STAT") != nullptr;
-            if (exact_stat) {       // diagnostics: level-0 blocks within the pyramid's reach (94 px for five bands) of a quadrant that is rendered
+            if (exact_stat) {       // diagnostics: level-0 blocks within the pyramid's reach (94 px for five bands) of a cell that is rendered
                 const int R0 = 94, nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
                 long cnt = 0;
                 for (int gy = 0; gy < nby; gy++)
                     for (int gx = 0; gx < nbx; gx++) {
                         const int x0 = C[0].x0 + gx * 64 - R0, x1 = C[0].x0 + gx * 64 + 63 + R0, y0 = C[0].y0 + gy * BHr - R0, y1 = C[0].y0 + gy * BHr + BHr - 1 + R0;
                         bool need = false;
-                        for (int qy = std::max(y0, 0) >> 7; qy <= (std::min(y1, crows - 1) >> 7) && !need; qy++)
-                            for (int qx = std::max(x0, 0) >> 7; qx <= (std::min(x1, ccols - 1) >> 7) && !need; qx++) {
-                                const uint64_t e = table_tmp_[(size_t)(qy >> 1) * tx + (qx >> 1)];
-                                need = e != 0 && !((e >> (1 + (qy & 1) * 2 + (qx & 1))) & 1);
+                        for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
+                            for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
+                                const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
+                                need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
                             }
                         cnt += need;
                     }
@@ -1099,11 +1104,11 @@ bool FusionMap::cull_frame_ok(const double M[9], int crows, int ccols) const
 }
 
 // The canvas lattice (64 (k - dil), 64 (m - dil)), k = 0 .. ccols / 64 + 2 dil, mapped into the source frame: position, squared distance
-// from the image centre, inside-the-frame flag.  A quadrant's dilated rectangle has its corners on it.  Points are mapped on first use
+// from the image centre, inside-the-frame flag.  A cell's dilated rectangle has its corners on it.  Points are mapped on first use
 // (a shard asks for an eighth of them); one division per point, no square root.
 void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil)
 {
-    lat_.dil = dil;                                             // dilation of a quadrant in lattice steps of 64 pixels
+    lat_.dil = dil;                                             // dilation of a cell in lattice steps of 64 pixels
     lat_.nx = ccols / 64 + 2 * dil + 1; lat_.ny = crows / 64 + 2 * dil + 1;
     const size_t n = (size_t)lat_.nx * lat_.ny;
     lat_.sx.resize(n); lat_.sy.resize(n); lat_.d.resize(n); lat_.in.assign(n, 2);          // 2: not mapped yet
@@ -1129,19 +1134,19 @@ inline size_t FusionMap::lattice_point(int k, int m)
 }
 
 // The radial weight (weightImage, .cpp:396-418, gathered at the NEAREST source pixel, 0 outside the frame) over the canvas rectangle with
-// lattice corners (k, m) .. (k + 2 + 2 dil, m + 2 + 2 dil) -- a quadrant of a tile dilated by 64 dil pixels -- against `wlb`, the lower
-// bound of what the quadrant stores:
-//   returns true when every weight the keyframe can have there is below wlb (the quadrant is out);
+// lattice corners (k, m) .. (k + span + 2 dil, m + span + 2 dil) -- a cell of a tile (span lattice steps on a side) dilated by 64 dil
+// pixels -- against `wlb`, the lower bound of what the cell stores:
+//   returns true when every weight the keyframe can have there is below wlb (the cell is out);
 //   *wmin <= every weight it has there (0 unless the rectangle maps wholly inside the frame).
 // The rectangle maps to a convex quadrilateral Q of the source plane (M is projective and W keeps its sign, cull_frame_ok); the weight
 // falls with the distance from the image centre c, so the largest weight sits at the point of Q nearest to c and the smallest at its
 // farthest corner.  "Largest weight < wlb" <=> dist(c, Q) > T, T the distance at which the weight -- with the margins below -- reaches
-// wlb; decided from the corners alone when one of them lies within T (most quadrants that stay in), by the exact point-to-quadrilateral
+// wlb; decided from the corners alone when one of them lies within T (most cells that stay in), by the exact point-to-quadrilateral
 // distance otherwise.  Margins: 2 source pixels for the nearest-pixel rounding (0.71) and the float arithmetic of the kernels, 1e-5 on
 // the weight for the pyramid's own rounding.
-bool FusionMap::quadrant_out(int k, int m, int weight_type, float wlb, bool want_out, float* wmin)
+bool FusionMap::cell_out(int k, int m, int span, int weight_type, float wlb, bool want_out, float* wmin)
 {
-    const int e = 2 + 2 * lat_.dil;                             // lattice steps across the dilated quadrant
+    const int e = span + 2 * lat_.dil;                          // lattice steps across the dilated cell
     const size_t c[4] = { lattice_point(k, m), lattice_point(k + e, m), lattice_point(k + e, m + e), lattice_point(k, m + e) };
     const double d2[4] = { lat_.d[c[0]], lat_.d[c[1]], lat_.d[c[2]], lat_.d[c[3]] };
     *wmin = 0.f;

@@ -29,8 +29,9 @@ struct Tile {
     bool  fresh = true;     // pyr_laplace[i].empty() (.cpp:498): first write copies unconditionally
     bool  changed = false;  // Ele::Ischanged
     // A lower bound of every weight stored in this tile, all levels (render_frame's cull): each keyframe whose canvas holds the
-    // tile raises it to the smallest weight that keyframe can have anywhere in the tile's pyramid support.  <= 0: nothing known.
-    float wlb[4] = { -1.f, -1.f, -1.f, -1.f };      // per quadrant of 128 x 128 pixels: 0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right
+    // tile raises it to the smallest weight that keyframe can have anywhere in the cell's pyramid support.  <= 0: nothing known.
+    // Per cell of the cull, row-major: 4 x 4 cells of 64 x 64 pixels (PF_CULL_SUB=2: 2 x 2 quadrants in the first four)
+    float wlb[16] = { -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f, -1.f };
 };
 
 class TileStore {
@@ -123,13 +124,13 @@ public:
     bool map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y);
     // the cull of render_frame (tiles in which a keyframe cannot win the select): see there
     bool cull_frame_ok(const double M[9], int crows, int ccols) const;
-    // source positions of the canvas lattice points (-64 + 64 k, -64 + 64 m) the quadrants' dilated rectangles have their corners on
+    // source positions of the canvas lattice points (-64 + 64 k, -64 + 64 m) the cells' dilated rectangles have their corners on
     void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil);
     size_t lattice_point(int k, int m);
-    bool quadrant_out(int k, int m, int weight_type, float wlb, bool want_out, float* wmin);
+    bool cell_out(int k, int m, int span, int weight_type, float wlb, bool want_out, float* wmin);
     long long culled_tiles() const { return n_culled_tiles_; }
     void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); cull_on_ = on; }       // default: on unless PF_CULL=0
-    long long culled_quadrants() const { return n_culled_quads_; }
+    long long culled_cells() const { return n_culled_cells_; }
     double level0_exact_px() const { return px_level0_exact_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
@@ -192,7 +193,8 @@ private:
     Pose   plane_{}, plane_inv_{};
     bool cull_on_ = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
     long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
-    long long n_culled_quads_ = 0;              // quadrants of rendered tiles switched off by it
+    long long n_culled_cells_ = 0;              // 64 x 64 cells of rendered tiles switched off by it
+    int cull_sub_ = (std::getenv("PF_CULL_SUB") && std::atoi(std::getenv("PF_CULL_SUB")) == 2) ? 2 : 4;      // cells per tile edge (A/B: 2 = quadrants)
     struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;

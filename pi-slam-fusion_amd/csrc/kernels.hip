@@ -591,16 +591,16 @@ __device__ __forceinline__ WT up_h_val(WT a, WT b, WT c, bool odd, bool le, bool
     return t;
 }
 
-// A tile-table entry = slot address (256-byte aligned) | flags: bit 0 fresh (first write copies unconditionally), bits 1..4 the
-// quadrants (128 x 128 level-0 pixels each: 1 = right half, 2 = lower half) in which this keyframe cannot win the max-weight select at
-// any level (the cull of FusionMap::render_frame): pixels there are not looked at -- they may have been computed from input that was
-// never produced.  Entries written without the cull carry no such bits.
-constexpr uint64_t kEntFlags = 0xff;
-__device__ __forceinline__ bool quadrant_culled(uint64_t ent, int x, int y, int ts)
+// A tile-table entry = slot address (256-byte aligned, below 2^48) | flags: bit 0 fresh (first write copies unconditionally), bits 48..63
+// the CELLS of the tile (64 x 64 level-0 pixels each, bit 48 + 4 * row + column) in which this keyframe cannot win the max-weight select
+// at any level (the cull of FusionMap::render_frame): pixels there are not looked at -- they may have been computed from input that was
+// never produced.  A pixel of level i belongs to the cell that holds its level-0 origin (x << i, y << i).  Entries written without the
+// cull carry no such bits.
+constexpr uint64_t kEntFlags = 0xffff0000000000ffull, kEntCells = 0xffff000000000000ull, kEntLow = 0xffull;
+__device__ __forceinline__ bool cell_culled(uint64_t ent, int x, int y, int ts, int sh)          // ts = 1 << sh: tile edge at this level
 {
-    const int hs = ts >> 1;                                   // a level of 1-pixel tiles has no quadrants
-    const int q = ((y & (ts - 1)) >= hs ? 2 : 0) | ((x & (ts - 1)) >= hs ? 1 : 0);
-    return hs != 0 && ((ent >> (1 + q)) & 1) != 0;
+    const int c = ((((y & (ts - 1)) << 2) >> sh) << 2) | (((x & (ts - 1)) << 2) >> sh);
+    return (((uint32_t)(ent >> 32) >> (16 + c)) & 1u) != 0;            // the high word alone: no 64-bit shift
 }
 
 // max-weight select of one pixel into its tile (Apply loop body, .cpp:496-551)
@@ -611,7 +611,7 @@ __device__ __forceinline__ void select_store(uint32_t lap_off, uint32_t w_off, i
     using T = typename Pix<F32>::T;
     const int sh = 8 - level, ts = kElePixels >> level;
     const uint64_t ent = table[(y >> sh) * tiles_x + (x >> sh)];
-    if (!ent || quadrant_culled(ent, x, y, ts)) return;
+    if (!ent || cell_culled(ent, x, y, ts, sh)) return;
     const uint64_t slot = ent & ~kEntFlags;
     const int loc = (y & (ts - 1)) * ts + (x & (ts - 1));
     float PF_GLOBAL* dw = (float PF_GLOBAL*)(slot + w_off) + loc;
@@ -947,7 +947,14 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         const int ti = (dy0 >> sh) * g.tiles_x + (dx0 >> sh);
         if (tab0) ent = ((const uint64_t PF_GLOBAL*)tab0)[ti];
         else ent = table[ti];
-        if (quadrant_culled(ent, dx0, dy0, ts)) ent = 0;
+        if (sh >= 3) { if (cell_culled(ent, dx0, dy0, ts, sh)) ent = 0; }       // cells of two pixels or more: the quad lies in one
+        else {                                                                   // single-pixel cells (a 4-pixel tile): per pixel, below
+            bool all = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) all = all && cell_culled(ent, dx0 + (k & 1), dy0 + (k >> 1), ts, sh);
+            if (all) ent = 0;
+        }
+        ent &= ~kEntCells;                                                       // from here on: slot address | fresh bit
     }
 
     // ---- A
@@ -1149,7 +1156,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
 
     // stored weights of the quad: in flight during stage B
     float dwv[2][2] = { { -1.f, -1.f }, { -1.f, -1.f } };           // fresh tile: every weight (>= 0) wins
-    const uint64_t slot = ent & ~kEntFlags;
+    const uint64_t slot = ent & ~kEntLow;
     const int loc0 = (dy0 & (ts - 1)) * ts + (dx0 & (ts - 1));
     if (ent && !(ent & 1)) {
         const float PF_GLOBAL* wp = (const float PF_GLOBAL*)(slot + lay.w_off) + loc0;
@@ -1159,6 +1166,13 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             const f2 v = *(const f2 PF_GLOBAL*)(wp + j * ts);
             dwv[j][0] = v.x; dwv[j][1] = v.y;
         }
+    }
+    if (sh < 3 && ent) {                                         // a quad across single-pixel cells (the entry read again: rare)
+        const int ti = (dy0 >> sh) * g.tiles_x + (dx0 >> sh);
+        const uint64_t e2 = tab0 ? ((const uint64_t PF_GLOBAL*)tab0)[ti] : table[ti];
+#pragma unroll
+        for (int k = 0; k < 4; k++)                               // no weight is >= NaN: those pixels never win
+            if (cell_culled(e2, dx0 + (k & 1), dy0 + (k >> 1), ts, sh)) dwv[k >> 1][k & 1] = __builtin_nanf("");
     }
 
     // ---- B: two vertically adjacent outputs per thread
@@ -1278,8 +1292,11 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
 
     // ---- D: 2x2 quad, Laplacian + max-weight select
     if (!ent) return;
-    const Px g00 = A[2 * qy + 4][0][qx + 2], g01 = A[2 * qy + 4][1][qx + 2];
-    const Px g10 = A[2 * qy + 5][0][qx + 2], g11 = A[2 * qy + 5][1][qx + 2];
+    int ry = dy0;                                                // the quad's row in A from dy0 (live anyway), not from a register kept since the top
+    asm volatile("" : "+v"(ry));
+    ry -= y0;
+    const Px g00 = A[ry + 4][0][qx + 2], g01 = A[ry + 4][1][qx + 2];
+    const Px g10 = A[ry + 5][0][qx + 2], g11 = A[ry + 5][1][qx + 2];
     const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
     const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
     const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
@@ -1417,9 +1434,9 @@ struct LevelJob {
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
 // in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
 // need_r0 (job 0, tile table in the arguments): instead of the need rectangles, a level-0 block decides for itself whether anything
-// rendered depends on it -- whether a quadrant that is rendered (entry != 0, quadrant flag clear) lies within need_r0 = 3 * 2^L - 2
+// rendered depends on it -- whether a cell that is rendered (entry != 0, cell flag clear) lies within need_r0 = 3 * 2^L - 2
 // pixels of it, the reach of the pyramid (`need` recursion of FusionMap::render_frame: pyrDown reads [2p-2, 2p+2], pyrUp +-1).
-// Exact at quadrant granularity, where eight bounding boxes are not (profiles/r04_ab.md).
+// Exact at cell granularity, where eight bounding boxes are not (profiles/r04_ab.md).
 struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1457,16 +1474,22 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
         if (b == 0) for (int i = threadIdx.x; i < batch.tab0_n; i += LNT) const_cast<uint64_t*>(J.table)[i] = tab0[i];
     }
     if (j == 0 && tab0 && batch.need_r0 && J.nrect) {
-        // job 0: is a rendered quadrant within the pyramid's reach of this block?
+        // job 0: is a rendered cell within the pyramid's reach of this block?  Tile by tile: the cells of the tile inside the reach
+        // as a 16-bit mask against the entry's culled cells
         const int bx = bb % J.g.nbx, by = bb / J.g.nbx, r0 = batch.need_r0;
         int x0 = J.g.cx0 + bx * LBW - r0, x1 = J.g.cx0 + bx * LBW + LBW - 1 + r0, y0 = J.g.cy0 + by * LBH - r0, y1 = J.g.cy0 + by * LBH + LBH - 1 + r0;
         x0 = x0 > 0 ? x0 : 0; y0 = y0 > 0 ? y0 : 0; x1 = x1 < J.g.cols - 1 ? x1 : J.g.cols - 1; y1 = y1 < J.g.rows - 1 ? y1 : J.g.rows - 1;
-        bool hit = false;
-        for (int qy = y0 >> 7; qy <= (y1 >> 7); qy++)
-            for (int qx = x0 >> 7; qx <= (x1 >> 7); qx++) {
-                const uint64_t e = tab0[(qy >> 1) * J.g.tiles_x + (qx >> 1)];
-                hit = hit || (e != 0 && !((e >> (1 + (qy & 1) * 2 + (qx & 1))) & 1));
-            }
+        // need_r0 <= 96: the reach spans two tiles a side at most -- four entries, the cells of each inside the reach as a 16-bit mask
+        const int cx0 = x0 >> 6, cx1 = x1 >> 6, cy0 = y0 >> 6, cy1 = y1 >> 6;
+        const int tx0 = cx0 >> 2, tx1 = cx1 >> 2, ty0 = cy0 >> 2, ty1 = cy1 >> 2;
+        auto cols = [](int a, int b) { return ((0xfu << a) & (0xfu >> (3 - b))) * 0x1111u; };
+        auto rows = [](int a, int b) { return (0xffffu << (4 * a)) & (0xffffu >> (4 * (3 - b))); };
+        const unsigned mx0 = cols(cx0 & 3, tx1 > tx0 ? 3 : cx1 & 3), mx1 = cols(tx1 > tx0 ? 0 : cx0 & 3, cx1 & 3);
+        const unsigned my0 = rows(cy0 & 3, ty1 > ty0 ? 3 : cy1 & 3), my1 = rows(ty1 > ty0 ? 0 : cy0 & 3, cy1 & 3);
+        const uint64_t e00 = tab0[ty0 * J.g.tiles_x + tx0], e01 = tab0[ty0 * J.g.tiles_x + tx1];
+        const uint64_t e10 = tab0[ty1 * J.g.tiles_x + tx0], e11 = tab0[ty1 * J.g.tiles_x + tx1];
+        auto rendered = [](uint64_t e, unsigned m) { return (int)(e != 0 && (~((uint32_t)(e >> 32) >> 16) & m) != 0); };
+        const bool hit = (rendered(e00, my0 & mx0) | rendered(e01, my0 & mx1) | rendered(e10, my1 & mx0) | rendered(e11, my1 & mx1)) != 0;
         if (!hit) return;
     } else
     if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
@@ -1715,6 +1738,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     static const bool no_need_r0 = getenv("PF_NO_NEED_R0") != nullptr;                              // A/B: the need rectangles for job 0 too
     if (!no_need_r0 && batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0 && batch.tab0_n && batch.job[0].nrect && BH == 32)
         batch.need_r0 = 3 * (1 << (lay.nlev - 1)) - 2;
+    if (batch.need_r0 > 96) batch.need_r0 = 0;                    // beyond five bands the reach spans more than two tiles: the rectangles
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {

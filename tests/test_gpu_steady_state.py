@@ -164,3 +164,22 @@ def test_cull_leaves_results_and_changed_flags_alone(pf, orc, force_float):
     for (ix, iy), img in list(zip(coords, px))[:: max(1, len(coords) // 8)]:
         assert np.array_equal(img, o.blend_tile(ix, iy)), (ix, iy)
     g.close()
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_cull_with_seven_bands_single_pixel_cells(pf, orc, force_float):
+    """Seven bands: the pyramid's reach is 382 px (the need rectangles instead of the in-kernel test), the cull's cells are dilated by
+    256 px, and at level 6 a tile is 4 x 4 pixels -- one pixel per cell, so that a 2x2 quad of the select lies across cells and is
+    gated per pixel; level 7 (2 x 2) goes through the top-level select.  Map2D.Scale = 4: a canvas of ~12 x 9 tiles."""
+    wl = workloads()
+    poses = sortie(24, seed=9)
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, fused=1, scale=4.0, band_number=7)
+    o = orc.OracleMap(force_float=force_float, scale=4.0, band_num=7)
+    assert g.prepare(wl.IDENTITY_PLANE, CAM, poses[:12]) and o.prepare(wl.IDENTITY_PLANE, CAM, poses[:12])
+    assert g.num_levels == 8
+    for k, p in enumerate(poses):
+        assert g.feed(frame(k), p) and o.feed(frame(k), p)
+    assert g.sync()
+    assert g.culled_cells() > 100 and g.culled_tiles() > 10, (g.culled_cells(), g.culled_tiles())
+    assert compare_maps(g, o) == []
+    g.close()

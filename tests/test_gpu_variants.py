@@ -7,6 +7,7 @@ tests in a child process (the switches are read once per process):
   PF_STRIPS=1        the wave-specialised rolling-strip form (profiles/r04_strips.md)
   PF_BLOCK28=1       64x28 blocks
   PF_CULL=0          every tile of every canvas rendered (no cull)
+  PF_CULL_SUB=2      the cull per quadrant of a tile instead of per 64 x 64 cell
 Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:311-558 (renderFrame)."""
 import os
 import subprocess
@@ -22,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # fall-back to the default form
 FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
         "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
-        "PF_CULL=0": "culled == 0 and c[0] > 0"}
+        "PF_CULL=0": "culled == 0 and c[0] > 0", "PF_CULL_SUB=2": "culled > 0 and g.culled_cells() % 4 == 0 and c[0] > 0"}
 PROBE = """
 import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
 import ctypes as C, numpy as np
@@ -43,7 +44,7 @@ assert %s, (c, culled)
 """
 
 
-@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_STRIPS", "PF_BLOCK28", "PF_CULL=0"])
+@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_STRIPS", "PF_BLOCK28", "PF_CULL=0", "PF_CULL_SUB=2"])
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
