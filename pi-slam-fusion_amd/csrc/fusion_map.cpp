@@ -757,10 +757,18 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 owned_all++;
                 unsigned out = 0;                                  // 64 x 64 cells in which this keyframe cannot win (bit 4 * row + column)
                 if (cull) {
+                    // the whole tile first, against the smallest of its cells' bounds: out there is out in every cell (the tile's dilated
+                    // rectangle holds each cell's) -- most culled cells lie in such tiles, and only their wmin is still worked out
+                    bool tile_out = false;
+                    if (!t->fresh) {
+                        float wl = t->wlb[0], unused;
+                        for (int q = 1; q < S * S; q++) wl = std::min(wl, t->wlb[q]);
+                        tile_out = cell_out(4 * x, 4 * y, 4, opt_.weight_type, wl, true, &unused);
+                    }
                     for (int q = 0; q < S * S; q++) {
                         const int qx = q % S, qy = q / S;
                         float wmin;
-                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, t->wlb[q], !t->fresh, &wmin))
+                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, t->wlb[q], !t->fresh && !tile_out, &wmin) || tile_out)
                             out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
                         if (wmin > t->wlb[q]) raise.push_back(Raise{ t, q, wmin });
                     }
