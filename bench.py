@@ -335,6 +335,7 @@ def main():
     ap.add_argument("--no-pre", action="store_true",
                     help="do not fly the 20 - W keyframes of the sortie's first line before the warm-up: a short run then times that "
                          "first line (every tile new, nothing culled), as round 2's driver record did")
+    ap.add_argument("--pre", type=int, default=None, help="keyframes of the sortie flown before the warm-up (default 20 - W: its first line)")
     args = ap.parse_args()
     if args.no_cull:
         os.environ["PF_CULL"] = "0"          # read when a map is created
@@ -368,7 +369,7 @@ def main():
     # SURVEY 8d / BASELINE.md cfg-2 times the keyframes AFTER the first 20 of the sortie (its first flight line, where every
     # tile is new).  A run with fewer warm-up steps than that (the driver's --steps 20 --warmup 5) flies the missing
     # 20 - W keyframes during setup, untimed, so that every K / W times the same part of the sortie: interior flight lines.
-    PRE = 0 if args.no_pre else max(0, 20 - W)
+    PRE = 0 if args.no_pre else (max(0, 20 - W) if args.pre is None else max(0, args.pre))
     n_traj = K + W + PRE
     extra = {} if args.fused is None else {"fused": args.fused}
 
