@@ -33,10 +33,25 @@ __device__ __forceinline__ double clamp_int_range(double v)
 // tile slots are reached through integers of the tile table: tell the compiler they are global
 // memory, otherwise every tile access becomes a FLAT instruction
 #define PF_GLOBAL __attribute__((address_space(1)))
+// Build switches for the A/B of cache hints (does GW_1 of launch k survive in the 256 MiB Infinity Cache until
+// launch k+1 reads it when the streams that are used once are marked non-temporal?  profiles/r04_ab.md):
+//   PF_NT_STORES  Laplacian payload stores      PF_NT_W  stored-weight loads and stores      PF_NT_SRC  the warp's frame gathers
 #ifdef PF_NT_STORES
 #define PF_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define PF_STORE(p, v) (*(p) = (v))
+#endif
+#ifdef PF_NT_W
+#define PF_STORE_W(p, v) __builtin_nontemporal_store((v), (p))
+#define PF_LOAD_W(p) __builtin_nontemporal_load(p)
+#else
+#define PF_STORE_W(p, v) (*(p) = (v))
+#define PF_LOAD_W(p) (*(p))
+#endif
+#ifdef PF_NT_SRC
+#define PF_LOAD_SRC(p) __builtin_nontemporal_load(p)
+#else
+#define PF_LOAD_SRC(p) (*(p))
 #endif
 
 template <bool F32> struct Pix;
@@ -472,7 +487,7 @@ __device__ __forceinline__ WarpTaps warp_fetch_pre(const uint8_t* __restrict__ s
     }
     const uint32_t off0 = ta.off0, off1 = ta.off1;
     flags |= ta.flags;
-    const u2 b0 = *(const u2*)(src + off0), b1 = *(const u2*)(src + off1);
+    const u2 b0 = PF_LOAD_SRC((const u2*)(src + off0)), b1 = PF_LOAD_SRC((const u2*)(src + off1));
     t.lo0 = b0.x; t.hi0 = b0.y; t.lo1 = b1.x; t.hi1 = b1.y;
     t.X = X; t.Y = Y; t.flags = flags;
     return t;
@@ -1163,7 +1178,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             typedef float f2 __attribute__((ext_vector_type(2)));
-            const f2 v = *(const f2 PF_GLOBAL*)(wp + j * ts);
+            const f2 v = PF_LOAD_W((const f2 PF_GLOBAL*)(wp + j * ts));
             dwv[j][0] = v.x; dwv[j][1] = v.y;
         }
     }
@@ -1339,10 +1354,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
             const float o11c = g11.c[2] - ((ho2[1] + ho2[2]) * 4) * (1.f / 64);
             // Laplacian payload: written once, read again only by blend/save -- non-temporal when PF_NT_STORES is defined (A/B)
             auto st3 = [&](T PF_GLOBAL* p, float a, float b, float c2) { PF_STORE(p, a); PF_STORE(p + 1, b); PF_STORE(p + 2, c2); };
-            if (s00) { st3(dl, o00L.x, o00L.y, o00c); dw[0] = g00.w; }
-            if (s01) { st3(dl + 3, o01L.x, o01L.y, o01c); dw[1] = g01.w; }
-            if (s10) { st3(dl + 3 * ts, o10L.x, o10L.y, o10c); dw[ts] = g10.w; }
-            if (s11) { st3(dl + 3 * ts + 3, o11L.x, o11L.y, o11c); dw[ts + 1] = g11.w; }
+            if (s00) { st3(dl, o00L.x, o00L.y, o00c); PF_STORE_W(&dw[0], g00.w); }
+            if (s01) { st3(dl + 3, o01L.x, o01L.y, o01c); PF_STORE_W(&dw[1], g01.w); }
+            if (s10) { st3(dl + 3 * ts, o10L.x, o10L.y, o10c); PF_STORE_W(&dw[ts], g10.w); }
+            if (s11) { st3(dl + 3 * ts + 3, o11L.x, o11L.y, o11c); PF_STORE_W(&dw[ts + 1], g11.w); }
             return;
         }
     }
@@ -1362,10 +1377,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         auto px2 = [](const Px& q, ss2& c01, ss2& c2p) { const PxP& v = reinterpret_cast<const PxP&>(q); c01 = (ss2)v.c01; c2p = (ss2)v.c2p; };
         ss2 a01, a2p;
         auto st3p = [&](T PF_GLOBAL* p, ss2 c01, ss2 c2p) { PF_STORE(p, c01.x); PF_STORE(p + 1, c01.y); PF_STORE(p + 2, c2p.x); };
-        if (s00) { px2(g00, a01, a2p); st3p(dl, a01 - up_e(he01[0], he01[1], he01[2]), a2p - up_e(he2p[0], he2p[1], he2p[2])); dw[0] = g00.w; }
-        if (s01) { px2(g01, a01, a2p); st3p(dl + 3, a01 - up_e(ho01[0], ho01[1], ho01[2]), a2p - up_e(ho2p[0], ho2p[1], ho2p[2])); dw[1] = g01.w; }
-        if (s10) { px2(g10, a01, a2p); st3p(dl + 3 * ts, a01 - up_o(he01[1], he01[2]), a2p - up_o(he2p[1], he2p[2])); dw[ts] = g10.w; }
-        if (s11) { px2(g11, a01, a2p); st3p(dl + 3 * ts + 3, a01 - up_o(ho01[1], ho01[2]), a2p - up_o(ho2p[1], ho2p[2])); dw[ts + 1] = g11.w; }
+        if (s00) { px2(g00, a01, a2p); st3p(dl, a01 - up_e(he01[0], he01[1], he01[2]), a2p - up_e(he2p[0], he2p[1], he2p[2])); PF_STORE_W(&dw[0], g00.w); }
+        if (s01) { px2(g01, a01, a2p); st3p(dl + 3, a01 - up_e(ho01[0], ho01[1], ho01[2]), a2p - up_e(ho2p[0], ho2p[1], ho2p[2])); PF_STORE_W(&dw[1], g01.w); }
+        if (s10) { px2(g10, a01, a2p); st3p(dl + 3 * ts, a01 - up_o(he01[1], he01[2]), a2p - up_o(he2p[1], he2p[2])); PF_STORE_W(&dw[ts], g10.w); }
+        if (s11) { px2(g11, a01, a2p); st3p(dl + 3 * ts + 3, a01 - up_o(ho01[1], ho01[2]), a2p - up_o(ho2p[1], ho2p[2])); PF_STORE_W(&dw[ts + 1], g11.w); }
         return;
     }
     WT he[3][3], ho[3][3];                                   // [row][channel]: even / odd output column
@@ -1392,10 +1407,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         o11[k] = sat_sub(g11.c[k], cast_up((ho[1][k] + ho[2][k]) * 4));
     }
     auto st3g = [&](T PF_GLOBAL* p, const T* v) { PF_STORE(p, v[0]); PF_STORE(p + 1, v[1]); PF_STORE(p + 2, v[2]); };
-    if (s00) { st3g(dl, o00); dw[0] = g00.w; }
-    if (s01) { st3g(dl + 3, o01); dw[1] = g01.w; }
-    if (s10) { st3g(dl + 3 * ts, o10); dw[ts] = g10.w; }
-    if (s11) { st3g(dl + 3 * ts + 3, o11); dw[ts + 1] = g11.w; }
+    if (s00) { st3g(dl, o00); PF_STORE_W(&dw[0], g00.w); }
+    if (s01) { st3g(dl + 3, o01); PF_STORE_W(&dw[1], g01.w); }
+    if (s10) { st3g(dl + 3 * ts, o10); PF_STORE_W(&dw[ts], g10.w); }
+    if (s11) { st3g(dl + 3 * ts + 3, o11); PF_STORE_W(&dw[ts + 1], g11.w); }
 }
 
 // XCD-aware block order: consecutive block ids go round-robin to the 8 XCDs, so block id b is mapped
