@@ -1421,6 +1421,15 @@ __device__ __forceinline__ int xcd_order(int b, int nblk)
     return (per > 0 && b < per * 8) ? (b & 7) * per + (b >> 3) : b;
 }
 
+// ... in runs of C consecutive blocks (a run = C neighbours along a row of the job's grid): round robin over the XCDs run by run
+__device__ __forceinline__ int xcd_chunks(int b, int nblk, int C)
+{
+    const int full = (nblk / (8 * C)) * (8 * C);
+    if (b >= full) return b;
+    const int k = b >> 3;
+    return ((k / C) * 8 + (b & 7)) * C + k % C;
+}
+
 // one pyramid level of one frame per launch (pf_options.fused = 3)
 template <bool F32, bool FROM_WARP, int LBH, int LNT>
 __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g, FusedWarp wa, const uint8_t* __restrict__ src,
@@ -1479,7 +1488,8 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
     // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
     // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
-    const int bb = ((J.nrect && !batch.rect_runs) || batch.rect_runs == 2) ? b : xcd_order(b, nblk);
+    const int bb = batch.rect_runs >= 3 ? xcd_chunks(b, nblk, 1 << (batch.rect_runs - 1)) :        // A/B: runs of 4 / 8 / 16 blocks per XCD
+                   ((J.nrect && !batch.rect_runs) || batch.rect_runs == 2) ? b : xcd_order(b, nblk);
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
     // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
