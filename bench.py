@@ -262,6 +262,14 @@ def strong_probe(pf, wl, torch, dist, rank, N, dev, frames, base, W, K, scale, f
 
 
 # ------------------------------------------------------------------------------ GPU legs
+def canvas_shares(m):
+    rs = m.render_stats(); ct = m.culled_tiles(); cc = m.culled_cells()
+    canvas = rs["owned_px"] + ct * 65536.0
+    if canvas <= 0:
+        return {}
+    return {"rendered_share_rank0": round(1.0 - (ct * 16 + cc) * 4096.0 / canvas, 4), "level0_run_share_rank0": round(rs["level0_px"] / canvas, 4)}
+
+
 def timed_run(m, run, W, K, event_every, barrier):
     """W untimed steps with every kernel timed (finds the dominant kernel), then K timed steps with HIP events
     around every n-th launch of that kernel only.  Returns (seconds, dominant kernel, its record, warm-up records)."""
@@ -494,7 +502,11 @@ def main():
                        "rendered_rank0": st["rendered"],
                        # tiles of the timed keyframes' canvases left out of the launches because the keyframe cannot win the max-weight
                        # select anywhere in them (geometric bound, results identical to the full render; PF_CULL=0 renders them all)
-                       "culled_tiles_rank0": m.culled_tiles()},
+                       "culled_tiles_rank0": m.culled_tiles(),
+                       # over all keyframes this map was fed: share of the canvases' pixels in cells that were rendered, and share of
+                       # them the level-0 blocks that ran covered (rendered cells + the pyramid's reach around them).  roofline.achieved
+                       # keeps SURVEY 8d's bytes for EVERY tile of every canvas in its numerator; roofline.traffic is what moved
+                       **canvas_shares(m)},
             "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0),
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
