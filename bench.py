@@ -129,7 +129,8 @@ def cpu_baseline(wl, poses, prep, frames_host, force_float, budget_s=15.0, max_f
             break
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 4), "unit": "keyframes/s", "cores": 1, "kind": "port",
-            "sample": "first %d frames of the same 4000x3000 workload, 1 thread, %.1f s" % (n, dt)}
+            "sample": "first %d frames of the same 4000x3000 sortie (its first flight line and the start of the second, where the GPU's "
+                      "timed range begins; the restatement renders every tile of every canvas either way), 1 thread, %.1f s" % (n, dt)}
 
 
 def map2dcpu_rates(pf, wl, poses, prep, frames_dev, frames_host, budget_s=8.0):
