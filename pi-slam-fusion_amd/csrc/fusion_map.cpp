@@ -997,6 +997,29 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                         cnt += need;
                     }
                 px_level0_exact_ += (double)cnt * 64 * BHr;
+                // the same question for the upper levels: blocks inside the need rectangles against blocks within the pyramid's reach of a
+                // rendered cell (printed every 100 keyframes)
+                static double up_rect[kMaxLevels] = {}, up_exact[kMaxLevels] = {}; static long up_n = 0;
+                for (int i = 1; i < L; i++) {
+                    const int reach = ((3 << (L - i)) - 2) << i, nbxi = (C[i].x1 - C[i].x0 + 63) / 64, nbyi = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+                    for (int gy = 0; gy < nbyi; gy++)
+                        for (int gx = 0; gx < nbxi; gx++) {
+                            bool inr = false;
+                            for (int k = 0; k < nrect[i]; k++) inr = inr || (gx >= rects[i][k].x0 && gx < rects[i][k].x1 && gy >= rects[i][k].y0 && gy < rects[i][k].y1);
+                            up_rect[i] += inr;
+                            const int x0 = ((C[i].x0 + gx * 64) << i) - reach, x1 = ((C[i].x0 + gx * 64 + 64) << i) - 1 + reach;
+                            const int y0 = ((C[i].y0 + gy * BHr) << i) - reach, y1 = ((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach;
+                            bool need = false;
+                            for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
+                                for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
+                                    const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
+                                    need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
+                                }
+                            up_exact[i] += need;
+                        }
+                }
+                if (++up_n % 100 == 0)
+                    for (int i = 1; i < L; i++) std::fprintf(stderr, "upper level %d: blocks in rectangles %.1f, within reach of a rendered cell %.1f per keyframe\n", i, up_rect[i] / up_n, up_exact[i] / up_n);
             }
         } else
             px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
