@@ -780,6 +780,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                     }
                     if (out) { culled_any = true; n_culled_cells_ += __builtin_popcount(out); }
                 }
+                if ((uint64_t)(uintptr_t)t->base >> 48) { set_error("tile slot address above 2^48: the table entry has no room for the cell flags"); return false; }
                 ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u) | ((uint64_t)out << 48);
                 touched.push_back(t);
                 owned++;
