@@ -697,15 +697,16 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     // The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
     Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
     const bool sharded = opt_.shard_count > 1;
-    // Cull (round 4): a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- its
-    // table entry stays 0, exactly as if another shard owned it, and the need rectangles below shrink the grid to what the
-    // remaining tiles depend on.  Nothing changes in what is stored: `if (srcW >= dstW)` (.cpp:521, :542) is false at every pixel
-    // of such a tile.  Sound because both sides are bounded from the geometry alone, with margins (quadrant_out):
-    //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the tile dilated by the pyramid's
+    // Cull (round 4): a cell of a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- a
+    // tile whose cells are all out keeps table entry 0, exactly as if another shard owned it, and the level-0 blocks' own need test / the
+    // need rectangles below shrink the grid to what the remaining cells depend on.  Nothing changes in what is stored: `if (srcW >= dstW)`
+    // (.cpp:521, :542) is false at every pixel of such a cell.  Sound because both sides are bounded from the geometry alone, with margins
+    // (cell_out):
+    //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the cell dilated by the pyramid's
     //                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
     //   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
-    //                 dilated tile, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
-    //                 then S_i > W_i^f.  Tile::wlb[quadrant] = max over f of wmin_f.
+    //                 dilated cell, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
+    //                 then S_i > W_i^f.  Tile::wlb[cell] = max over f of wmin_f.
     // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
     double Minv[9];
     const bool cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
@@ -730,7 +731,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     std::vector<Tile*> touched;
     touched.reserve((size_t)tx * ty);
     int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0, owned_all = 0;
-    // the same box in level-0 pixels, around the quadrants that are rendered (== the tiles' box when nothing is culled); cells likewise
+    // the same box in level-0 pixels, around the cells that are rendered (== the tiles' box when nothing is culled); the squares of the rectangles likewise
     int pbx0 = 1 << 30, pbx1 = 0, pby0 = 1 << 30, pby1 = 0;
     auto add_rect = [&](int sx, int sy, int x0, int y0, int x1, int y1) {
         pbx0 = std::min(pbx0, x0); pbx1 = std::max(pbx1, x1); pby0 = std::min(pby0, y0); pby1 = std::max(pby1, y1);

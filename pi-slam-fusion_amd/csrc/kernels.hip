@@ -1058,7 +1058,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                 // a pixel takes its taps from the patch when (ux, ux+1) x (uy, uy+1) lie inside it; an empty patch takes none
                 const unsigned okw = pw > 1 && ph > 1 ? (unsigned)(pw - 1) : 0u, okh = pw > 1 && ph > 1 ? (unsigned)(ph - 1) : 0u;
                 // coordinates exactly as warp_fetch_pre's common case (the host checked that every pixel of this canvas is
-                // "tame": FusedWarp::plain == 2), then: do both taps' rows and columns lie inside the staged patch?
+                // "tame": patch_plan / tame_canvas), then: do both taps' rows and columns lie inside the staged patch?
                 auto coords = [&](int y) {
                     const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
                     const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
