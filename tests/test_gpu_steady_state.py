@@ -108,10 +108,12 @@ def test_table_copy_twin(pf, force_float):
     assert a == b
 
 
-def test_bench_sortie_pipelined_equals_per_op(pf):
+@pytest.mark.parametrize("force_float", [1, 0])
+def test_bench_sortie_pipelined_equals_per_op(pf, force_float):
     """bench.py's cfg-A sortie (4000x3000, 225 keyframes resident in HBM): the pipelined path (fused=1, the one
-    the headline is timed on) and the one-kernel-per-reference-op path (fused=0, oracle-checked at small sizes
-    and on 4000x3000 frames in test_gpu_at_size.py) must build the same map, tile for tile."""
+    the headline is timed on -- with the cull of render_frame, which the other path does not have) and the
+    one-kernel-per-reference-op path (fused=0, oracle-checked at small sizes and on 4000x3000 frames in
+    test_gpu_at_size.py) must build the same map, tile for tile, for both pyramid types."""
     torch = pytest.importorskip("torch")
     wl = workloads()
     cam = [4000, 3000, 3000, 3000, 2000, 1500]
@@ -122,7 +124,7 @@ def test_bench_sortie_pipelined_equals_per_op(pf):
     torch.cuda.synchronize()
     digests = []
     for fused in (1, 0):
-        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, fused=fused)
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, fused=fused)
         assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
         for k, p in enumerate(poses):
             assert m.feed_device(frames[k % 4].data_ptr(), 3000, 4000, p)
