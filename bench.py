@@ -65,10 +65,11 @@ def pose_at(poses, n):
 
 
 def event_every_for(steps, requested=None):
-    """HIP events around every n-th launch: about 8 timed launches whatever --steps is."""
+    """HIP events around every n-th launch: about 5 timed launches whatever --steps is (an event pair costs the stream ~2 us:
+    profiles/r04_ab.md measured 129.5 / 127.4 us per step with every 2nd / 5th launch of a 20-step run bracketed)."""
     if requested is not None:
         return max(0, requested)
-    return max(1, steps // 8)
+    return max(1, steps // 5)
 
 
 def guarded(fn, *a, **kw):
@@ -336,7 +337,7 @@ def main():
     ap.add_argument("--fused", type=int, default=None, help="pf_options.fused (default: the library's default)")
     ap.add_argument("--event-every", type=int, default=None,
                     help="HIP events around every n-th launch of the dominant kernel in the timed region "
-                         "(default steps//8; each event pair costs stream time; 0 = none, no roofline)")
+                         "(default steps//5; each event pair costs stream time; 0 = none, no roofline)")
     ap.add_argument("--no-strong-probe", action="store_true", help="N > 1, --shard weak: skip the tile-sharded sub-measurement")
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 8)")
