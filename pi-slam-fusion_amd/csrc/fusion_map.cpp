@@ -924,6 +924,42 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         // applied per cell); blocks outside every rectangle exit at once.  (Unsharded: every block is needed, no rectangles.)
         BlockRect rects[kMaxLevels][kMaxRects];
         int nrect[kMaxLevels] = {};
+        int need_n_tmp[kMaxLevels] = {};
+        // Upper levels: one bit per block of the level's grid -- does a rendered cell lie within the pyramid's reach of it (the rule the
+        // level-0 blocks apply to themselves in the kernel: (3 * 2^(L-i) - 2) level-i pixels)?  From row bitmaps of the rendered cells
+        // (canvases up to 32 tiles wide); the jobs carry them in their launches' kernel arguments, the rectangles stay as the fallback.
+        if ((sharded || culled_any) && !cells_overflow && 4 * tx <= 128 && L >= 2) {
+            const int BHr = level_block_rows(lay_.f32 != 0);
+            typedef unsigned __int128 u128;
+            cell_rows_.assign((size_t)4 * ty, 0);
+            for (int y = 0; y < ty; y++)
+                for (int x = 0; x < tx; x++) {
+                    const uint64_t e = table_tmp_[(size_t)y * tx + x];
+                    if (!e) continue;
+                    const unsigned in = ~(unsigned)(e >> 48) & 0xffffu;
+                    for (int r = 0; r < 4; r++) cell_rows_[(size_t)4 * y + r] |= (u128)((in >> (4 * r)) & 15u) << (4 * x);
+                }
+            for (int i = 1; i < L; i++) {
+                const int reach = ((3 << (L - i)) - 2) << i, nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+                need_n_tmp[i] = 0;
+                if (nbx <= 0 || nby <= 0 || (nbx * nby + 31) / 32 > kNeedWords) continue;
+                uint32_t* bits = need_tmp_[i];
+                std::memset(bits, 0, sizeof(uint32_t) * (size_t)((nbx * nby + 31) / 32));
+                for (int gy = 0; gy < nby; gy++) {
+                    const int y0 = std::max(((C[i].y0 + gy * BHr) << i) - reach, 0) >> 6, y1 = std::min((((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach) >> 6, 4 * ty - 1);
+                    u128 rowsum = 0;
+                    for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
+                    if (!rowsum) continue;
+                    for (int gx = 0; gx < nbx; gx++) {
+                        const int x0 = std::max(((C[i].x0 + gx * 64) << i) - reach, 0) >> 6, x1 = std::min((((C[i].x0 + gx * 64 + 64) << i) - 1 + reach) >> 6, 4 * tx - 1);
+                        if (x0 > x1) continue;
+                        const u128 m = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
+                        if (rowsum & m) { const int b = gy * nbx + gx; bits[(size_t)b >> 5] |= 1u << (b & 31); }
+                    }
+                }
+                need_n_tmp[i] = nbx * nby;
+            }
+        }
         double owned_tiles = owned_all, blocks_run0 = 0;          // algorithmic bytes: every canvas tile of this rank, culled or not
         if ((sharded || culled_any) && opt_.fused == 1 && !cells_overflow) {
             const int BHr = level_block_rows(lay_.f32 != 0);
@@ -974,7 +1010,13 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 for (int k = 0; k < nrect[i]; k++) rects[i][k] = BlockRect{ (short)v[k].x0, (short)v[k].y0, (short)v[k].x1, (short)v[k].y1 };
                 if (v.empty()) { nrect[i] = 1; rects[i][0] = BlockRect{ 0, 0, 0, 0 }; }      // nothing needed at this level: an empty rectangle
             }
-            {   // level-0 blocks that run (render_stats, bench --shard strong)
+            if (need_n_tmp[1] > 0 && level0_need_reach(lay_, table_args ? tx * ty : 0, nrect[0]) > 0) {
+                // the level-0 blocks pick themselves in the kernel (within 94 px of a rendered cell): counted through the level-1 bitmap, whose
+                // blocks are 2 x 2 of them under nearly the same rule (92 px)
+                int n1 = 0;
+                for (int w = 0; w < (need_n_tmp[1] + 31) / 32; w++) n1 += __builtin_popcount(need_tmp_[1][w]);
+                blocks_run0 = std::min(4.0 * n1, (double)((C[0].x1 - C[0].x0 + 63) / 64) * ((C[0].y1 - C[0].y0 + BHr - 1) / BHr));
+            } else {   // level-0 blocks that run (render_stats, bench --shard strong)
                 const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
                 block_bits_.assign((size_t)std::max(nbx, 0) * std::max(nby, 0), 0);
                 for (int k = 0; k < nrect[0]; k++)
@@ -1037,6 +1079,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 cur.bytes[i] = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0) + (i == 0 ? (double)a.src_cn * f.rows * f.cols : 0);
             }
             if (table_args) { cur.table_args = table_tmp_.data(); cur.table_n = tx * ty; }
+            for (int i = 1; i < L; i++) { cur.need_n[i] = need_n_tmp[i]; if (need_n_tmp[i] > 0) std::memcpy(cur.need_bits[i], need_tmp_[i], sizeof(uint32_t) * (size_t)((need_n_tmp[i] + 31) / 32)); }
             if (!launch_pipeline(&cur, &a, src)) return false;
         } else {
         // fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
@@ -1283,6 +1326,7 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.table_args = i == 0 ? fr.table_args : nullptr; q.table_n = i == 0 ? fr.table_n : 0;
         q.nrect = fr.nrect[i];
         for (int k = 0; k < fr.nrect[i]; k++) q.rect[k] = fr.rect[i][k];
+        q.need_bits = i > 0 && fr.need_n[i] > 0 ? fr.need_bits[i] : nullptr; q.need_n = i > 0 ? fr.need_n[i] : 0;
         bytes += fr.bytes[i];
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid

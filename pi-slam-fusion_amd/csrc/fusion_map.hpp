@@ -240,8 +240,11 @@ private:
     struct Win { int x0, x1, y0, y1; };
     struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels];
                        int nrect[kMaxLevels]; BlockRect rect[kMaxLevels][kMaxRects];        // LevelLaunch::rect of each level
+                       uint32_t need_bits[kMaxLevels][kNeedWords]; int need_n[kMaxLevels] = {};    // LevelLaunch::need_bits of the upper levels (need_n 0: none)
                        const uint64_t* table_args = nullptr; int table_n = 0; };            // level 0 only, valid during render_frame
     PipeFrame pipe_[kMaxLevels];
+    uint32_t need_tmp_[kMaxLevels][kNeedWords];     // render_frame scratch: the upper levels' need bitmaps of the keyframe being fed
+    std::vector<unsigned __int128> cell_rows_;      // render_frame scratch: rendered cells of the canvas, one 128-bit row per cell row
     unsigned long long launch_seq_ = 0;             // parity selects the GW buffer set a launch writes
     bool flushing_ = false;
     bool launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const uint8_t* src);

@@ -1454,6 +1454,7 @@ struct LevelJob {
     int from_warp;             // level 0: stage A is the warp of the launch's frame
     int nrect;                 // see LevelLaunch::rect
     BlockRect rect[kMaxRects];
+    int bits_off;              // first word of the job's need bitmap in LevelBatch::need_bits, -1: none (the rectangles decide)
 };
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
 // in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
@@ -1461,7 +1462,8 @@ struct LevelJob {
 // rendered depends on it -- whether a cell that is rendered (entry != 0, cell flag clear) lies within need_r0 = 3 * 2^L - 2
 // pixels of it, the reach of the pyramid (`need` recursion of FusionMap::render_frame: pyrDown reads [2p-2, 2p+2], pyrUp +-1).
 // Exact at cell granularity, where eight bounding boxes are not (profiles/r04_ab.md).
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; uint64_t tab0[kArgTable]; };
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
+static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 2 * sizeof(void*) <= 4096, "kernel arguments of k_levels: 4 KB");
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
@@ -1516,6 +1518,9 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
         auto rendered = [](uint64_t e, unsigned m) { return (int)(e != 0 && (~((uint32_t)(e >> 32) >> 16) & m) != 0); };
         const bool hit = (rendered(e00, my0 & mx0) | rendered(e01, my0 & mx1) | rendered(e10, my1 & mx0) | rendered(e11, my1 & mx1)) != 0;
         if (!hit) return;
+    } else
+    if (J.bits_off >= 0) {                                     // an upper-level job with its need bitmap in the kernel arguments
+        if (!((batch.need_bits[J.bits_off + (bb >> 5)] >> (bb & 31)) & 1u)) return;
     } else
     if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
         const int bx = bb % J.g.nbx, by = bb / J.g.nbx;
@@ -1684,6 +1689,7 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
         J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
         for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        J.bits_off = -1;
         if (batch.njobs == 0 && q.table_args && q.table_n > 0 && q.table_n <= kArgTable) {
             batch.tab0_n = q.table_n;
             for (int i = 0; i < q.table_n; i++) batch.tab0[i] = q.table_args[i];
@@ -1723,13 +1729,23 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
     return true;
 }
 
+int level0_need_reach(const TileLayout& lay, int table_n, int nrect0)
+{
+    static const bool off = getenv("PF_NO_NEED_R0") != nullptr;                                 // A/B: the need rectangles for job 0 too
+    static const bool strips = getenv("PF_STRIPS") && atoi(getenv("PF_STRIPS")) != 0;             // the strip form keeps the rectangles
+    if (off || strips || table_n <= 0 || table_n > kArgTable || nrect0 <= 0 || level_block_rows(lay.f32 != 0) != 32) return 0;
+    const int r0 = 3 * (1 << (lay.nlev - 1)) - 2;
+    return r0 <= 96 ? r0 : 0;                                     // beyond five bands the reach spans more than two tiles: the rectangles
+}
+
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
 {
     if (level_block_rows(lay.f32 != 0) == 32 && launch_strips(s, lay, jobs, njobs, wa, src)) return;
     static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const int BH = level_block_rows(lay.f32 != 0);
     LevelBatch batch{};
-    int first_blocks = 0, upper_blocks = 0;
+    int first_blocks = 0, upper_blocks = 0, bits_words = 0;
+    static const bool use_bits = getenv("PF_NO_NEED_BITS") == nullptr;       // A/B: the rectangles for the upper levels
     for (int k = 0; k < njobs; k++) {
         const LevelLaunch& q = jobs[k];
         LevelJob& J = batch.job[batch.njobs];
@@ -1741,6 +1757,12 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
         J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
         for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        J.bits_off = -1;
+        if (use_bits && !q.from_warp && q.need_bits && q.need_n == J.g.nbx * J.g.nby && bits_words + (q.need_n + 31) / 32 <= kNeedWords) {
+            J.bits_off = bits_words;
+            for (int w = 0; w < (q.need_n + 31) / 32; w++) batch.need_bits[bits_words + w] = q.need_bits[w];
+            bits_words += (q.need_n + 31) / 32;
+        }
         if (batch.njobs == 0 && q.table_args && q.table_n > 0 && q.table_n <= kArgTable) {
             batch.tab0_n = q.table_n;
             for (int i = 0; i < q.table_n; i++) batch.tab0[i] = q.table_args[i];
@@ -1760,10 +1782,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     batch.sequential = upper_first ? 2 : !interleave;
     static const int rect_runs = getenv("PF_RECT_ORDER") ? atoi(getenv("PF_RECT_ORDER")) : 0;      // 1: XCD runs even with rectangles; 2: round robin always (A/B)
     batch.rect_runs = rect_runs;
-    static const bool no_need_r0 = getenv("PF_NO_NEED_R0") != nullptr;                              // A/B: the need rectangles for job 0 too
-    if (!no_need_r0 && batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0 && batch.tab0_n && batch.job[0].nrect && BH == 32)
-        batch.need_r0 = 3 * (1 << (lay.nlev - 1)) - 2;
-    if (batch.need_r0 > 96) batch.need_r0 = 0;                    // beyond five bands the reach spans more than two tiles: the rectangles
+    if (batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0) batch.need_r0 = level0_need_reach(lay, batch.tab0_n, batch.job[0].nrect);
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {

@@ -77,7 +77,8 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
 // Pipelined form of the same kernel: ONE launch carries several independent level jobs (level 0 of the
 // newest frame, level 1 of the frame before it, ...), each with its own tile table and GW buffers.
 constexpr int kArgTable = 256;      // tile-table entries that can travel inside the kernel arguments of a launch
-constexpr int kMaxRects = 8;        // need rectangles per level job (tile-sharded canvases)
+constexpr int kMaxRects = 4;        // need rectangles per level job (tile-sharded canvases, the cull); 8 until the need bitmaps took their room in the kernel arguments
+constexpr int kNeedWords = 100;     // 32-bit words of need bitmaps a launch can carry for its upper-level jobs (kernel arguments are 4 KB)
 struct BlockRect { short x0, y0, x1, y1; };      // [x0,x1) x [y0,y1) in blocks of the job's block grid
 struct LevelLaunch {
     int level, rows, cols;          // pyramid level and its canvas extent
@@ -93,11 +94,18 @@ struct LevelLaunch {
     // tile-sharded canvases: the union of these rectangles holds every block something owned by this rank depends on;
     // the other blocks of the grid exit at once.  nrect == 0: every block runs.
     int nrect; BlockRect rect[kMaxRects];
+    // upper-level jobs: one bit per block of the job's grid (row-major, nbx = ceil((cx1 - cx0) / 64)), set where something rendered depends
+    // on the block; travels in the kernel arguments when the launch's jobs fit kNeedWords together, and the rectangles are not looked at then
+    const uint32_t* need_bits = nullptr; int need_n = 0;
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);
 void read_form_counts(long long out[8]);                          // launches of the pipelined kernel by form (kernels.hip, g_form_counts)
 int  read_select_counts(unsigned long long* out, int reset);       // diagnostics (PF_STAMP=1): [2*level] pixels stage D saw, [2*level+1] pixels that won
+// Reach (level-0 pixels) of the test by which the level-0 blocks of a pipelined launch decide for themselves whether they run (k_levels,
+// LevelBatch::need_r0): 0 when the launch takes the need rectangles instead.  table_n: entries of the frame's tile table if it travels in
+// the kernel arguments (0: it does not); nrect0: rectangles of the level-0 job.
+int  level0_need_reach(const TileLayout& lay, int table_n, int nrect0);
 int  level_block_rows(bool f32);                                     // block height of the pipelined level kernel (fused = 1)      // diagnostics (PF_STAMP=1)
 
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
