@@ -991,11 +991,12 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 }
             }
             for (int i = 0; i < L; i++) {
-                // at most kMaxRects travel with a job: merge the pair whose common bounding box adds the fewest blocks
+                // at most kMaxRects (level 0) / kMaxRectsUpper travel with a job: merge the pair whose common bounding box adds the fewest blocks
                 // (extra blocks only cost time: they hold no owned pixel and write no tile)
                 std::vector<R>& v = lv[i];
                 auto area = [](const R& r) { return (long)(r.x1 - r.x0) * (r.y1 - r.y0); };
-                while ((int)v.size() > kMaxRects) {
+                const int cap = i == 0 ? kMaxRects : kMaxRectsUpper;       // what a job of this level can carry (kernels.hpp)
+                while ((int)v.size() > cap) {
                     size_t ba = 0, bb = 1; long best = -1;
                     for (size_t p = 0; p < v.size(); p++)
                         for (size_t q = p + 1; q < v.size(); q++) {

@@ -1453,7 +1453,7 @@ struct LevelJob {
     int first;                 // first block id
     int from_warp;             // level 0: stage A is the warp of the launch's frame
     int nrect;                 // see LevelLaunch::rect
-    BlockRect rect[kMaxRects];
+    BlockRect rect[kMaxRectsUpper];   // job 0 of a launch: LevelBatch::rect0 instead (up to kMaxRects)
     int bits_off;              // first word of the job's need bitmap in LevelBatch::need_bits, -1: none (the rectangles decide)
 };
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
@@ -1462,7 +1462,7 @@ struct LevelJob {
 // rendered depends on it -- whether a cell that is rendered (entry != 0, cell flag clear) lies within need_r0 = 3 * 2^L - 2
 // pixels of it, the reach of the pyramid (`need` recursion of FusionMap::render_frame: pyrDown reads [2p-2, 2p+2], pyrUp +-1).
 // Exact at cell granularity, where eight bounding boxes are not (profiles/r04_ab.md).
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; BlockRect rect0[kMaxRects]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 2 * sizeof(void*) <= 4096, "kernel arguments of k_levels: 4 KB");
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1525,7 +1525,10 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
     if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
         const int bx = bb % J.g.nbx, by = bb / J.g.nbx;
         bool hit = false;
-        for (int k = 0; k < J.nrect; k++) hit = hit || (bx >= J.rect[k].x0 && bx < J.rect[k].x1 && by >= J.rect[k].y0 && by < J.rect[k].y1);
+        for (int k = 0; k < J.nrect; k++) {
+            const BlockRect r = j == 0 ? batch.rect0[k] : J.rect[k < kMaxRectsUpper ? k : 0];
+            hit = hit || (bx >= r.x0 && bx < r.x1 && by >= r.y0 && by < r.y1);
+        }
         if (!hit) return;
     }
     unsigned long long* st = nullptr;
@@ -1687,8 +1690,19 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
         if ((q.cx0 | q.cy0 | q.cy1) & 1) return false;          // strips start on even columns / rows (they always do: regions are tile- or 2x-aligned)
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
-        J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
-        for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        // job 0 keeps its rectangles in LevelBatch::rect0 (up to kMaxRects), the others in their own (kMaxRectsUpper; more than that -- the
+        // host does not produce them -- become their common bounding box: a superset is always right)
+        {
+            const int cap = batch.njobs == 0 ? kMaxRects : kMaxRectsUpper;
+            J.nrect = q.nrect;
+            if (q.nrect > cap) {
+                BlockRect u = q.rect[0];
+                for (int r = 1; r < q.nrect && r < kMaxRects; r++) { u.x0 = std::min(u.x0, q.rect[r].x0); u.y0 = std::min(u.y0, q.rect[r].y0); u.x1 = std::max(u.x1, q.rect[r].x1); u.y1 = std::max(u.y1, q.rect[r].y1); }
+                J.nrect = 1;
+                if (batch.njobs == 0) batch.rect0[0] = u; else J.rect[0] = u;
+            } else
+                for (int r = 0; r < q.nrect; r++) { if (batch.njobs == 0) batch.rect0[r] = q.rect[r]; else J.rect[r] = q.rect[r]; }
+        }
         J.bits_off = -1;
         if (batch.njobs == 0 && q.table_args && q.table_n > 0 && q.table_n <= kArgTable) {
             batch.tab0_n = q.table_n;
@@ -1755,8 +1769,19 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
-        J.nrect = q.nrect < kMaxRects ? q.nrect : kMaxRects;
-        for (int r = 0; r < J.nrect; r++) J.rect[r] = q.rect[r];
+        // job 0 keeps its rectangles in LevelBatch::rect0 (up to kMaxRects), the others in their own (kMaxRectsUpper; more than that -- the
+        // host does not produce them -- become their common bounding box: a superset is always right)
+        {
+            const int cap = batch.njobs == 0 ? kMaxRects : kMaxRectsUpper;
+            J.nrect = q.nrect;
+            if (q.nrect > cap) {
+                BlockRect u = q.rect[0];
+                for (int r = 1; r < q.nrect && r < kMaxRects; r++) { u.x0 = std::min(u.x0, q.rect[r].x0); u.y0 = std::min(u.y0, q.rect[r].y0); u.x1 = std::max(u.x1, q.rect[r].x1); u.y1 = std::max(u.y1, q.rect[r].y1); }
+                J.nrect = 1;
+                if (batch.njobs == 0) batch.rect0[0] = u; else J.rect[0] = u;
+            } else
+                for (int r = 0; r < q.nrect; r++) { if (batch.njobs == 0) batch.rect0[r] = q.rect[r]; else J.rect[r] = q.rect[r]; }
+        }
         J.bits_off = -1;
         if (use_bits && !q.from_warp && q.need_bits && q.need_n == J.g.nbx * J.g.nby && bits_words + (q.need_n + 31) / 32 <= kNeedWords) {
             J.bits_off = bits_words;

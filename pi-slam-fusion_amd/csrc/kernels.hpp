@@ -77,7 +77,8 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
 // Pipelined form of the same kernel: ONE launch carries several independent level jobs (level 0 of the
 // newest frame, level 1 of the frame before it, ...), each with its own tile table and GW buffers.
 constexpr int kArgTable = 256;      // tile-table entries that can travel inside the kernel arguments of a launch
-constexpr int kMaxRects = 4;        // need rectangles per level job (tile-sharded canvases, the cull); 8 until the need bitmaps took their room in the kernel arguments
+constexpr int kMaxRects = 8;        // need rectangles of a level-0 job (tile-sharded canvases, the cull): what LevelLaunch can hold
+constexpr int kMaxRectsUpper = 4;   // ... of an upper-level job (their need bitmaps took the room in the kernel arguments; they are the fallback there)
 constexpr int kNeedWords = 100;     // 32-bit words of need bitmaps a launch can carry for its upper-level jobs (kernel arguments are 4 KB)
 struct BlockRect { short x0, y0, x1, y1; };      // [x0,x1) x [y0,y1) in blocks of the job's block grid
 struct LevelLaunch {
