@@ -69,7 +69,10 @@ def event_every_for(steps, requested=None):
     profiles/r04_ab.md measured 129.5 / 127.4 us per step with every 2nd / 5th launch of a 20-step run bracketed)."""
     if requested is not None:
         return max(0, requested)
-    return max(1, steps // 5)
+    n = max(1, steps // 5)
+    while n >= 10 and (n % 2 == 0 or n % 5 == 0):      # not in step with the sortie's 20 keyframes per flight line (every 40th launch is a turn)
+        n += 1
+    return n
 
 
 def guarded(fn, *a, **kw):

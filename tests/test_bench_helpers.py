@@ -22,7 +22,7 @@ def test_pose_indexing_wraps():
 def test_event_every_scales_with_steps():
     assert bench.event_every_for(20) == 4          # 5 timed launches under the driver's --steps 20
     assert bench.event_every_for(1) == 1
-    assert bench.event_every_for(200) == 40
+    assert bench.event_every_for(200) == 41         # not a multiple of the 20 keyframes of a flight line
     assert bench.event_every_for(200, 16) == 16 and bench.event_every_for(5, 0) == 0
 
 
