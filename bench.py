@@ -513,9 +513,16 @@ def main():
                        # keeps SURVEY 8d's bytes for EVERY tile of every canvas in its numerator; roofline.traffic is what moved
                        **canvas_shares(m)},
             "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0),
+            # the same bytes over the whole step instead of the launches bracketed by events: launches run back to back (gap 0 in the
+            # rocprofv3 trace), so a step IS a launch, and an event pair costs the launch it brackets several us (N = 1 only)
+            "roofline_per_step": None,
             "frame_alg_GBps": round(sum(v["alg_bytes"] for v in prof.values()) / max(W, 1) * (total_frames / dt) / max(1, N if not strong else 1) / 1e9, 1),
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
         }
+        r = out["roofline"]
+        if N == 1 and isinstance(r, dict) and r.get("alg_bytes_per_launch") and dt > 0:
+            a = r["alg_bytes_per_launch"] / (dt / K) / 1e9
+            out["roofline_per_step"] = {"achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "us_per_step": round(dt / K * 1e6, 2)}
 
     # strong sharding: what a rank renders beyond its share, and the timed seam exchange
     if strong:
