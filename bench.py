@@ -21,7 +21,7 @@ per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
 gets per GPU is the `host_feed` record of the same line (pf_feed with its 36 MB H2D copy inside: PCIe-bound, ~1500 keyframes/s).
 
 Rank 0 prints ONE JSON line (contract in the task statement), including
-  roofline     : dominant kernel, algorithmic bytes / HIP-event time on the map's stream
+  roofline     : dominant kernel, algorithmic bytes of what its launches processed / HIP-event time on the map's stream
   cpu_baseline : the oracle (CPU port of MultiBandMap2DCPU) timed on a bounded sample.
 Every leg after the timed GPU region is guarded: a failure there becomes {"error": ...} inside
 the line and never loses the GPU measurement.
@@ -95,9 +95,17 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_record(dtype_key, kernel):
-    """HBM traffic / VALU instructions per launch from the committed PMC passes (profiles/pmc_traffic.json),
-    with the build they were taken at; `current` says whether that is the device code being run."""
+def window_key(steps, warmup, pre, no_cull=False):
+    """Names the launches a PMC pass averaged over: the K timed launches of `bench.py --steps K --warmup W` with `pre` keyframes of the
+    sortie flown before the warm-up (tools/pmc_summary.py takes the same three numbers)."""
+    return "k%d_w%d_pre%d%s" % (steps, warmup, pre, "_nocull" if no_cull else "")
+
+
+def pmc_record(dtype_key, kernel, window=None):
+    """HBM traffic / VALU instructions per launch from the committed PMC passes (profiles/pmc_traffic.json), with the build they were
+    taken at; `current` says whether that is the device code being run.  The passes are keyed by WINDOW (window_key): counters of the
+    200-after-20 steady state say nothing about the driver's 20 keyframes at the turn into the second flight line, nor about a run with
+    the cull off -- a window without a pass of its own gets None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         tj = json.load(open(path))
@@ -108,8 +116,13 @@ def pmc_record(dtype_key, kernel):
         return None
     if not isinstance(rec, dict):
         rec = {"traffic": rec}
+    if "windows" in rec:
+        rec = rec["windows"].get(window)
+        if rec is None:
+            return None
     meta = tj.get("_meta", {})
     out = dict(rec)
+    out["window"] = window
     out["git_sha"] = meta.get("git_sha")
     out["kernels_sha"] = meta.get("kernels_sha")
     out["current"] = meta.get("kernels_sha") == kernels_sha()
@@ -299,20 +312,34 @@ def timed_run(m, run, W, K, event_every, barrier):
     return t1 - t0, dom, p, prof
 
 
-def roofline_record(dom, p, dtype_key, event_every, pmc_ok=True):
-    ach = p["alg_bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+def roofline_record(dom, p, dtype_key, event_every, pmc_ok=True, window=None):
+    """`achieved` / `frac`: the algorithmic bytes of what the timed launches PROCESSED (alg_bytes_run: SURVEY 8d's per-tile bytes x the
+    share of each level's canvas pixels covered by blocks that ran, + the frame read once) over their HIP-event time.  The cull leaves
+    blocks of a canvas out, so SURVEY 8d's bytes for every tile of the canvas (`frac_full_canvas`, what rounds 1-4 printed as `frac`) would
+    credit a launch with bytes it never touched.  `frac_delivered`: what the memory system moved (PMC traffic of the same window) over
+    the same time."""
+    secs = p["ms"] * 1e-3
+    run_bytes = p.get("alg_bytes_run", p["alg_bytes"])
+    ach = run_bytes / secs / 1e9 if secs > 0 else 0.0
+    ach_full = p["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0
     launches = max(p["launches"], 1)
     us = p["ms"] / launches * 1e3
-    pmc = pmc_record(dtype_key, dom) if pmc_ok else None      # the committed PMC passes are cfg-A's (Map2D.Scale = 1)
+    pmc = pmc_record(dtype_key, dom, window) if pmc_ok else None      # the committed PMC passes are cfg-A's (Map2D.Scale = 1)
     # "bound" names the roofline `achieved`/`peak` are priced against (HBM bytes: north_star asks for % of the HBM roofline);
     # "limiter" below says what the counters show the launch is actually held by
     rec = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(ach / HBM_PEAK_GBS, 4),
+           "frac_full_canvas": round(ach_full / HBM_PEAK_GBS, 4),
+           "frac_delivered": None,
            "traffic": pmc.get("traffic") if pmc else None,
-           "avg_launch_us": round(us, 2), "alg_bytes_per_launch": round(p["alg_bytes"] / launches),
-           "launches": p["launches"], "timed_every": event_every}
+           "avg_launch_us": round(us, 2), "alg_bytes_run_per_launch": round(run_bytes / launches),
+           "alg_bytes_per_launch": round(p["alg_bytes"] / launches),
+           "launches": p["launches"], "timed_every": event_every, "window": window}
     if pmc:
-        rec["pmc_build"] = {"git_sha": pmc.get("git_sha"), "kernels_sha": pmc.get("kernels_sha"), "current": pmc.get("current")}
+        if pmc.get("traffic") and us > 0:
+            rec["frac_delivered"] = round(pmc["traffic"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        rec["pmc_build"] = {"git_sha": pmc.get("git_sha"), "kernels_sha": pmc.get("kernels_sha"), "current": pmc.get("current"),
+                            "launches_averaged": pmc.get("launches")}
         if pmc.get("valu_insts") and us > 0:
             # a wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (MI355X_MICROARCH.md, cycle table)
             frac = pmc["valu_insts"] * 4.0 / (SIMDS * us * 1e-6 * MAX_CLOCK_GHZ * 1e9)
@@ -509,10 +536,11 @@ def main():
                        # select anywhere in them (geometric bound, results identical to the full render; PF_CULL=0 renders them all)
                        "culled_tiles_rank0": m.culled_tiles(),
                        # over all keyframes this map was fed: share of the canvases' pixels in cells that were rendered, and share of
-                       # them the level-0 blocks that ran covered (rendered cells + the pyramid's reach around them).  roofline.achieved
-                       # keeps SURVEY 8d's bytes for EVERY tile of every canvas in its numerator; roofline.traffic is what moved
+                       # them the level-0 blocks that ran covered (rendered cells + the pyramid's reach around them).  roofline.achieved / frac
+                       # count the bytes of what the launches' blocks processed (alg_bytes_run), frac_full_canvas SURVEY 8d's bytes for EVERY tile
+                       # of every canvas, roofline.traffic / frac_delivered what moved
                        **canvas_shares(m)},
-            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0),
+            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0, window_key(K, W, PRE, args.no_cull)),
             # the same bytes over the whole step instead of the launches bracketed by events: launches run back to back (gap 0 in the
             # rocprofv3 trace), so a step IS a launch, and an event pair costs the launch it brackets several us (N = 1 only)
             "roofline_per_step": None,
@@ -520,8 +548,8 @@ def main():
             "kernels_warmup_ms": {n: round(prof[n]["ms"], 3) for n in prof if prof[n]["launches"]},
         }
         r = out["roofline"]
-        if N == 1 and isinstance(r, dict) and r.get("alg_bytes_per_launch") and dt > 0:
-            a = r["alg_bytes_per_launch"] / (dt / K) / 1e9
+        if N == 1 and isinstance(r, dict) and r.get("alg_bytes_run_per_launch") and dt > 0:
+            a = r["alg_bytes_run_per_launch"] / (dt / K) / 1e9
             out["roofline_per_step"] = {"achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4), "us_per_step": round(dt / K * 1e6, 2)}
 
     # strong sharding: what a rank renders beyond its share, and the timed seam exchange
@@ -579,7 +607,7 @@ def main():
             dt2, dom2, p2, _ = timed_run(m2, make_run(m2), W, K, ev_every, barrier)
             k2 = "f32" if not force_float else "int16"
             rec = {"value": round(K / dt2, 3), "unit": "keyframes/s", "dtype": k2, "ms_per_step": round(dt2 / K * 1e3, 4),
-                   "roofline": roofline_record(dom2, p2, k2, ev_every, args.scale == 1.0)}
+                   "roofline": roofline_record(dom2, p2, k2, ev_every, args.scale == 1.0, window_key(K, W, PRE, args.no_cull))}
             m2.close()
             return rec
         out["int16" if force_float else "f32"] = guarded(other_dtype)

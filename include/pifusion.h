@@ -253,6 +253,12 @@ int      pf_dist_set_verify(pf_dist* d, int on);
 int     pf_profile_enable(pf_map* m, int mode);
 int     pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
                         double* alg_bytes);
+/* The same, plus alg_bytes_run: the algorithmic bytes of the part of the canvases the timed launches' blocks actually processed
+ * (SURVEY 8d's per-tile bytes x the share of each level's pixels covered by blocks that ran, + the frame read once).  The cull of
+ * render_frame and a shard leave blocks of a canvas out; alg_bytes counts every tile of every canvas regardless.  Equal to
+ * alg_bytes for kernels that always cover their whole window. */
+int     pf_profile_read_run(pf_map* m, int cap, const char** names, double* total_ms, long long* launches,
+                            double* alg_bytes, double* alg_bytes_run);
 int     pf_profile_reset(pf_map* m);
 /* sharding overhead since creation: {frames that put pixels on this rank, level-0 pixels computed (owned tiles + pyramid
  * halo, fused path), tile pixels owned in those frames, tiles held}: [1]/[2] is the halo recompute factor of a shard  */
@@ -274,6 +280,10 @@ long long pf_debug_culled_cells(pf_map* m);
 double  pf_debug_level0_exact_px(pf_map* m);
 /* The cull on (default, unless PF_CULL=0 is in the environment) or off: off renders every tile of every keyframe's canvas, as the
  * reference does; the mosaic is the same either way.  For measurements (bench.py reports both rates). */
+/* Test hook: the pf_feed / pf_feed_device calls (0-based, counted since creation, geometry-only feeds included) whose keyframes renderFrame
+ * accepted, in render order; writes the newest min(cap, count) of them and returns the count (at most the newest 65536 are kept).  With
+ * thread = 1 and a queue that drops (MultiBandMap2DCPU.cpp:300-303) this is the only way to tell a checker which keyframes the map holds. */
+int     pf_debug_render_log(pf_map* m, long long* out, int cap);
 void    pf_set_cull(pf_map* m, int on);
 /* Launches of the pipelined level kernel by form since the library was loaded: [0] block form with the computed weight (default),
  * [1] block form gathering the weight plane, [2] LDS-staged source patch, [3] rolling strips, [4] 64x64 blocks, [5] 64x28 blocks,

@@ -121,11 +121,16 @@ def lib():
                                      vp, C.c_int, ip, ip, C.c_int, ip]
     L.pf_profile_enable.argtypes = [vp, C.c_int]
     L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
+    # (PF_LIB may name an older build of the library for an A/B round, tools/ab.sh: it lacks this round's entry points)
+    if hasattr(L, "pf_profile_read_run") or not os.environ.get("PF_LIB"):
+        L.pf_profile_read_run.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp, dp]
     L.pf_profile_reset.argtypes = [vp]
     L.pf_stats.argtypes = [vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.pf_reserve_tiles.argtypes = [vp, C.c_longlong]
     L.pf_debug_culled_tiles.argtypes = [vp]; L.pf_debug_culled_tiles.restype = C.c_longlong
     L.pf_set_cull.argtypes = [vp, C.c_int]; L.pf_set_cull.restype = None
+    if hasattr(L, "pf_debug_render_log") or not os.environ.get("PF_LIB"):
+        L.pf_debug_render_log.argtypes = [vp, C.POINTER(C.c_longlong), C.c_int]
     L.pf_debug_culled_cells.argtypes = [vp]; L.pf_debug_culled_cells.restype = C.c_longlong
     L.pf_debug_level0_exact_px.argtypes = [vp]; L.pf_debug_level0_exact_px.restype = C.c_double
     L.pf_render_stats.argtypes = [vp, dp]
@@ -381,9 +386,13 @@ class Map2D:
 
     def profile_read(self):
         cap = 32
-        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_longlong * cap)(); by = (C.c_double * cap)()
-        k = lib().pf_profile_read(self._h, cap, names, ms, n, by)
-        return {names[i].decode(): {"ms": ms[i], "launches": n[i], "alg_bytes": by[i]} for i in range(k)}
+        names = (C.c_char_p * cap)(); ms = (C.c_double * cap)(); n = (C.c_longlong * cap)(); by = (C.c_double * cap)(); br = (C.c_double * cap)()
+        if not hasattr(lib(), "pf_profile_read_run"):          # PF_LIB = an older build (A/B rounds)
+            k = lib().pf_profile_read(self._h, cap, names, ms, n, by)
+            return {names[i].decode(): {"ms": ms[i], "launches": n[i], "alg_bytes": by[i], "alg_bytes_run": by[i]} for i in range(k)}
+        k = lib().pf_profile_read_run(self._h, cap, names, ms, n, by, br)
+        # alg_bytes: SURVEY 8d's bytes for every tile of every canvas; alg_bytes_run: for the part of the canvases the launches' blocks processed
+        return {names[i].decode(): {"ms": ms[i], "launches": n[i], "alg_bytes": by[i], "alg_bytes_run": br[i]} for i in range(k)}
 
     def reserve_tiles(self, n_tiles):
         """Allocator hint: HBM for n_tiles more tiles now (see pf_reserve_tiles)."""
@@ -407,6 +416,13 @@ class Map2D:
     def set_cull(self, on):
         """the cull of render_frame on / off (off: every tile of every canvas rendered, as the reference does; same mosaic)"""
         lib().pf_set_cull(self._h, 1 if on else 0)
+
+    def render_log(self):
+        """test hook: indices of the feed() calls whose keyframes were rendered, in render order (pf_debug_render_log)"""
+        n = lib().pf_debug_render_log(self._h, None, 0)
+        out = (C.c_longlong * max(n, 1))()
+        k = lib().pf_debug_render_log(self._h, out, n)
+        return [int(out[i]) for i in range(min(n, k))]
 
     def culled_tiles(self):
         """tiles left out of launches because the keyframe could not win the select anywhere in them (diagnostics)"""

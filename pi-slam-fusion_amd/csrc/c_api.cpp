@@ -60,6 +60,7 @@ int pf_feed(pf_map* m, const pf_image* img, const double pose[7]) { return m && 
 int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, true); }
 int pf_debug_phase_stamps(unsigned long long* out, int cap_blocks) { return pf::read_phase_stamps(out, cap_blocks); }
 void pf_debug_form_counts(long long out[8]) { if (out) pf::read_form_counts(out); }
+int pf_debug_render_log(pf_map* m, long long* out, int cap) { return m ? m->impl.render_log(out, cap) : 0; }
 void pf_set_cull(pf_map* m, int on) { if (m) m->impl.set_cull(on != 0); }
 long long pf_debug_culled_cells(pf_map* m) { return m ? m->impl.culled_cells() : 0; }
 double pf_debug_level0_exact_px(pf_map* m) { return m ? m->impl.level0_exact_px() : 0; }
@@ -230,6 +231,8 @@ int pf_dist_info(pf_dist* d, int* rank, int* nranks, const char** transport)
 int pf_profile_enable(pf_map* m, int mode) { if (!m) return 0; m->impl.profile_enable(mode); return 1; }
 int pf_profile_read(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes)
 { return m ? m->impl.profile_read(cap, names, total_ms, launches, alg_bytes) : 0; }
+int pf_profile_read_run(pf_map* m, int cap, const char** names, double* total_ms, long long* launches, double* alg_bytes, double* alg_bytes_run)
+{ return m ? m->impl.profile_read(cap, names, total_ms, launches, alg_bytes, alg_bytes_run) : 0; }
 int pf_profile_reset(pf_map* m) { if (!m) return 0; m->impl.profile_reset(); return 1; }
 int pf_reserve_tiles(pf_map* m, long long n_tiles) { return m && m->impl.reserve_tiles(n_tiles) ? 1 : 0; }
 int pf_render_stats(pf_map* m, double out4[4]) { if (!m || !out4) return 0; m->impl.render_stats(out4); return 1; }

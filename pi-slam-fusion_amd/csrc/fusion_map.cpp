@@ -237,7 +237,13 @@ hipError_t FusionMap::sync_all()
 // ---------------------------------------------------------------- profile
 void FusionMap::profile_enable(int mode) { std::lock_guard<std::mutex> l(mu_); prof_mode_ = mode; }
 
-void FusionMap::prof_begin(int id, double bytes, hipStream_t st)
+bool FusionMap::prof_would(int id) const
+{
+    const int what = prof_mode_ & 0xff, every = prof_mode_ >> 8;
+    return (what == 1 || what == 2 + id) && (every <= 1 || prof_tick_[id] % every == 0);
+}
+
+void FusionMap::prof_begin(int id, double bytes, hipStream_t st, double bytes_run)
 {
     prof_stream_ = st ? st : stream_;
     const int what = prof_mode_ & 0xff, every = prof_mode_ >> 8;
@@ -246,7 +252,7 @@ void FusionMap::prof_begin(int id, double bytes, hipStream_t st)
     if (prof_on_ && every > 1) prof_on_ = (prof_tick_[id]++ % every) == 0;
     if (!prof_on_) return;
     auto get = [&]() { hipEvent_t e; if (!ev_pool_.empty()) { e = ev_pool_.back(); ev_pool_.pop_back(); } else (void)hipEventCreate(&e); return e; };
-    prof_cur_ = { id, get(), get(), bytes };
+    prof_cur_ = { id, get(), get(), bytes, bytes_run < 0 ? bytes : bytes_run };
     (void)hipEventRecord(prof_cur_.a, prof_stream_);
 }
 
@@ -262,13 +268,13 @@ void FusionMap::prof_harvest()
 {
     for (auto& r : prof_pending_) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { prof_ms_[r.id] += ms; prof_n_[r.id]++; prof_bytes_[r.id] += r.bytes; }
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { prof_ms_[r.id] += ms; prof_n_[r.id]++; prof_bytes_[r.id] += r.bytes; prof_bytes_run_[r.id] += r.bytes_run; }
         ev_pool_.push_back(r.a); ev_pool_.push_back(r.b);
     }
     prof_pending_.clear();
 }
 
-int FusionMap::profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes)
+int FusionMap::profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes, double* bytes_run)
 {
     std::lock_guard<std::mutex> l(mu_);
     (void)hipSetDevice(device_);
@@ -277,6 +283,7 @@ int FusionMap::profile_read(int cap, const char** names, double* ms, long long* 
     int n = 0;
     for (int i = 0; i < K_COUNT && n < cap; i++, n++) {
         names[n] = kernel_name(i); ms[n] = prof_ms_[i]; launches[n] = prof_n_[i]; bytes[n] = prof_bytes_[i];
+        if (bytes_run) bytes_run[n] = prof_bytes_run_[i];
     }
     return n;
 }
@@ -287,7 +294,7 @@ void FusionMap::profile_reset()
     (void)hipSetDevice(device_);
     (void)sync_all();
     prof_harvest();
-    for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; prof_tick_[i] = 0; }
+    for (int i = 0; i < K_COUNT; i++) { prof_ms_[i] = 0; prof_n_[i] = 0; prof_bytes_[i] = 0; prof_bytes_run_[i] = 0; prof_tick_[i] = 0; }
 }
 
 // Allocator hint (no reference counterpart: the reference's tiles are cv::Mat on the heap): slabs for n more tiles
@@ -453,6 +460,7 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
     if (!init_ok_) { set_error("feed: no device"); return false; }
     Section sec(this, T_FEED);
     QueuedFrame f{};
+    { std::lock_guard<std::mutex> q(qmu_); f.seq = feed_seq_++; }
     {
         std::lock_guard<std::mutex> l(mu_);
         if (!valid_) return false;
@@ -802,6 +810,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
         for (Tile* t : culled) t->changed = true;
         if (owned_all) n_rendered_++;
+        if (f.seq >= 0) { if (render_log_.size() >= 65536) render_log_.erase(render_log_.begin(), render_log_.begin() + 32768); render_log_.push_back(f.seq); }
         return true;
     }
     px_owned_ += (double)owned * kElePixels * kElePixels;     // what this rank renders beyond its share: owned tile pixels vs the level-0 window (bench --shard strong)
@@ -1069,6 +1078,46 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         } else
             px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
         if (opt_.fused == 1) {
+            // Share of each level's canvas pixels (this rank's tiles) that the blocks which RUN cover: 1 unless the cull or a shard leaves
+            // blocks out.  Level 0 with the blocks' own need test (k_levels, need_r0): the same rule evaluated here from the rendered cells'
+            // row bitmaps -- exactly, for the launches that are bracketed by events (10 us of host time), through the level-1 bitmap otherwise.
+            double run_share[kMaxLevels];
+            for (int i = 0; i < kMaxLevels; i++) run_share[i] = 1.0;
+            if ((sharded || culled_any) && !cells_overflow) {
+                const int BHr = level_block_rows(lay_.f32 != 0);
+                for (int i = 0; i < L; i++) {
+                    const int nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+                    if (nbx <= 0 || nby <= 0) continue;
+                    double run = 0;
+                    const int r0 = i == 0 && need_n_tmp[1] > 0 ? level0_need_reach(lay_, table_args ? tx * ty : 0, nrect[0]) : 0;
+                    if (i == 0 && r0 > 0 && prof_would(K_LEVEL0) && cell_rows_.size() == (size_t)4 * ty) {
+                        typedef unsigned __int128 u128;
+                        for (int gy = 0; gy < nby; gy++) {
+                            const int y0 = std::max(C[0].y0 + gy * BHr - r0, 0) >> 6, y1 = std::min(C[0].y0 + gy * BHr + BHr - 1 + r0, crows - 1) >> 6;
+                            u128 rowsum = 0;
+                            for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
+                            if (!rowsum) continue;
+                            for (int gx = 0; gx < nbx; gx++) {
+                                const int x0 = std::max(C[0].x0 + gx * 64 - r0, 0) >> 6, x1 = std::min(C[0].x0 + gx * 64 + 63 + r0, ccols - 1) >> 6;
+                                if (x0 > x1) continue;
+                                const u128 m = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
+                                run += (rowsum & m) != 0;
+                            }
+                        }
+                    } else if (i == 0) run = blocks_run0;
+                    else if (need_n_tmp[i] > 0) { for (int w = 0; w < (need_n_tmp[i] + 31) / 32; w++) run += __builtin_popcount(need_tmp_[i][w]); }
+                    else {
+                        block_bits_.assign((size_t)nbx * nby, 0);
+                        for (int k = 0; k < nrect[i]; k++)
+                            for (int gy = std::max<int>(rects[i][k].y0, 0); gy < std::min<int>(rects[i][k].y1, nby); gy++)
+                                for (int gx = std::max<int>(rects[i][k].x0, 0); gx < std::min<int>(rects[i][k].x1, nbx); gx++) block_bits_[(size_t)gy * nbx + gx] = 1;
+                        for (uint8_t v : block_bits_) run += v;
+                        if (!nrect[i]) run = (double)nbx * nby;
+                    }
+                    const double ts = kElePixels >> i;
+                    run_share[i] = std::min(1.0, run * 64.0 * BHr / std::max(1.0, owned_tiles * ts * ts));
+                }
+            }
             // one launch per keyframe: this frame's level 0 plus the pending upper levels of the frames before it
             PipeFrame cur;
             cur.valid = true; cur.ring = ring; cur.tx = tx; cur.crows = crows; cur.ccols = ccols;
@@ -1077,7 +1126,9 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                 for (int k = 0; k < nrect[i]; k++) cur.rect[i][k] = rects[i][k];
                 const double ts = kElePixels >> i, n = owned_tiles * ts * ts;
                 // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
-                cur.bytes[i] = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0) + (i == 0 ? (double)a.src_cn * f.rows * f.cols : 0);
+                const double tile_bytes = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0), frame_bytes_read = i == 0 ? (double)a.src_cn * f.rows * f.cols : 0;
+                cur.bytes[i] = tile_bytes + frame_bytes_read;                         // every canvas tile of this rank, culled or not
+                cur.bytes_run[i] = tile_bytes * run_share[i] + frame_bytes_read;      // the part of the canvas whose blocks run
             }
             if (table_args) { cur.table_args = table_tmp_.data(); cur.table_n = tx * ty; }
             for (int i = 1; i < L; i++) { cur.need_n[i] = need_n_tmp[i]; if (need_n_tmp[i] > 0) std::memcpy(cur.need_bits[i], need_tmp_[i], sizeof(uint32_t) * (size_t)((need_n_tmp[i] + 31) / 32)); }
@@ -1160,7 +1211,16 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     for (Tile* t : culled) t->changed = true;
     for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
     n_rendered_++;
+    if (f.seq >= 0) { if (render_log_.size() >= 65536) render_log_.erase(render_log_.begin(), render_log_.begin() + 32768); render_log_.push_back(f.seq); }
     return true;
+}
+
+int FusionMap::render_log(long long* out, int cap)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    const int n = (int)std::min<size_t>(render_log_.size(), (size_t)std::max(cap, 0));
+    for (int i = 0; i < n; i++) out[i] = render_log_[render_log_.size() - (size_t)n + (size_t)i];
+    return (int)render_log_.size();
 }
 
 // May this frame's tiles be culled?  Only for a tame map: every canvas corner (with the pyramid halo) in front of the camera and
@@ -1245,19 +1305,20 @@ bool FusionMap::cell_out(int k, int m, int span, int weight_type, float wlb, boo
     // (weight type 0: wmin can exceed wlb only if the farthest corner lies within (1 - 1e-5 - wlb) dis_max - 2 of the centre -- in the steady
     // state it rarely does, and the square root is not taken)
     const double far2 = std::max(std::max(d2[0], d2[1]), std::max(d2[2], d2[3]));
-    const double tw = weight_type == 0 ? (1.0 - 1e-5 - (double)wlb) * lat_.dis_max - 2.0 : 1e300;
+    const double mpx = cull_margin_px_, mw = cull_margin_w_;       // 2 source pixels, 1e-5 (see the header)
+    const double tw = weight_type == 0 ? (1.0 - mw - (double)wlb) * lat_.dis_max - mpx : 1e300;
     if ((lat_.in[c[0]] & lat_.in[c[1]] & lat_.in[c[2]] & lat_.in[c[3]]) == 1 && tw > 0 && far2 < tw * tw * (1.0 + 1e-9)) {
-        const double dfar = std::sqrt(far2) + 2.0;
+        const double dfar = std::sqrt(far2) + mpx;
         double w = 1.0 - dfar * lat_.inv_dis_max;
         if (weight_type != 0) w = w > 0 ? w * w : 0.0;
-        w -= 1e-5;
+        w -= mw;
         if (w > 2e-5) *wmin = (float)w;
     }
     if (!want_out || !(wlb > 2e-5f)) return false;                // nothing known about the stored weights (or a fresh tile): in
-    // T: weight(T - 2) + 1e-5 == wlb
-    double g = (double)wlb - 1e-5;
+    // T: weight(T - mpx) + mw == wlb
+    double g = (double)wlb - mw;
     if (weight_type != 0) g = std::sqrt(g);
-    const double T = 2.0 + lat_.dis_max * (1.0 - g), T2 = T * T;
+    const double T = mpx + lat_.dis_max * (1.0 - g), T2 = T * T;
     if (d2[0] <= T2 || d2[1] <= T2 || d2[2] <= T2 || d2[3] <= T2) return false;      // a corner within T
     bool pos = true, neg = true; double dnear2 = 1e300;
     for (int i = 0; i < 4; i++) {
@@ -1315,7 +1376,7 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
     DevBuf* in  = par ? gw_ : gw2_;
     LevelLaunch jobs[kMaxLevels];
     int n = 0;
-    double bytes = 0;
+    double bytes = 0, bytes_run = 0;
     auto add = [&](const PipeFrame& fr, int i) {
         const bool top = (i + 1 == L);
         LevelLaunch& q = jobs[n++];
@@ -1328,14 +1389,14 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
         q.nrect = fr.nrect[i];
         for (int k = 0; k < fr.nrect[i]; k++) q.rect[k] = fr.rect[i][k];
         q.need_bits = i > 0 && fr.need_n[i] > 0 ? fr.need_bits[i] : nullptr; q.need_n = i > 0 ? fr.need_n[i] : 0;
-        bytes += fr.bytes[i];
+        bytes += fr.bytes[i]; bytes_run += fr.bytes_run[i];
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid
     if (cur) add(*cur, 0);
     static const bool no_upper = std::getenv("PF_NO_UPPER") != nullptr;       // diagnostics (timing only, wrong tiles): what the upper-level jobs add to a launch
     for (int s = 1; s < L; s++) if (pipe_[s].valid && !no_upper) add(pipe_[s], s);
     if (n) {
-        prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_);
+        prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_, bytes_run);
         launch_levels(stream_, lay_, jobs, n, wa, src);
         prof_end();
         HIP_OK(hipGetLastError());

@@ -74,6 +74,7 @@ struct QueuedFrame {
     long   step;
     int    rows, cols, cn;  // cn: 3 = BGR8, 4 = BGRA8
     Pose   pose;            // plane coordinates
+    long long seq = -1;     // number of the feed() call that brought it (test hook: render_log)
 };
 
 // Named host sections, after pi::Timer (PIL/src/base/time/Timer.h:43-85: enter / leave, calls, min / max / mean per
@@ -131,6 +132,9 @@ public:
     long long culled_tiles() const { return n_culled_tiles_; }
     void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); cull_on_ = on; }       // default: on unless PF_CULL=0
     long long culled_cells() const { return n_culled_cells_; }
+    // test hook: the feed() calls (0-based, counted since creation) whose keyframes renderFrame accepted, in render order -- with thread = true
+    // and a queue that drops, the only way to tell an oracle which keyframes the map really holds; the newest 65536
+    int  render_log(long long* out, int cap);
     double level0_exact_px() const { return px_level0_exact_; }
     bool high_quality() const { return opt_.high_quality_show != 0 && !single_band_; }
 
@@ -150,7 +154,7 @@ public:
     bool tile_import(int ix, int iy, const void* dev_in);
 
     void profile_enable(int mode);
-    int  profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes);
+    int  profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes, double* bytes_run = nullptr);
     void profile_reset();
     void stats(long long* rendered, long long* rejected, long long* dropped);
     void render_stats(double out[4]);
@@ -171,7 +175,10 @@ private:
     int  acquire_slot(size_t bytes);
     bool upload(const pf_image* img, int slot);
     bool blend_batch(const std::vector<std::pair<int,int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host);
-    void prof_begin(int id, double bytes, hipStream_t st = nullptr);
+    // bytes: SURVEY 8d's algorithmic bytes of the launch for EVERY tile of the canvas; bytes_run (< 0: the same): those of the part of the
+    // canvas its blocks actually process (the cull / a shard leave blocks out) -- the numerator of bench.py's roofline.frac
+    void prof_begin(int id, double bytes, hipStream_t st = nullptr, double bytes_run = -1);
+    bool prof_would(int id) const;                                 // will the next prof_begin(id) bracket its launch with events?
     hipError_t sync_all();
     void prof_end();
     void prof_harvest();
@@ -194,6 +201,12 @@ private:
     bool cull_on_ = !(std::getenv("PF_CULL") && std::atoi(std::getenv("PF_CULL")) == 0);
     long long n_culled_tiles_ = 0;              // tiles left out of launches by the cull (diagnostics)
     long long n_culled_cells_ = 0;              // 64 x 64 cells of rendered tiles switched off by it
+    // Margins of the cull's bounds (cell_out): source pixels added to / taken from a distance before it becomes a weight (the nearest-pixel
+    // rounding of the weight gather, 0.71 px, and the float arithmetic of the kernels), and what is taken from / added to a weight (the
+    // pyramid's own rounding).  PF_CULL_MARGIN_PX / PF_CULL_MARGIN_W override them for the sensitivity runs of tools/cull_soak.py
+    // (profiles/r05_cull_margins.md: mismatches against the oracle per setting -- the safety factor, measured); defaults 2 px, 1e-5.
+    double cull_margin_px_ = std::getenv("PF_CULL_MARGIN_PX") ? std::atof(std::getenv("PF_CULL_MARGIN_PX")) : 2.0;
+    double cull_margin_w_ = std::getenv("PF_CULL_MARGIN_W") ? std::atof(std::getenv("PF_CULL_MARGIN_W")) : 1e-5;
     int cull_sub_ = (std::getenv("PF_CULL_SUB") && std::atoi(std::getenv("PF_CULL_SUB")) == 2) ? 2 : 4;      // cells per tile edge (A/B: 2 = quadrants)
     struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
     Camera cam_{};
@@ -238,7 +251,7 @@ private:
 
     // pipelined level launches (opt_.fused == 1): pipe_[s] is the frame whose level s runs in the next launch
     struct Win { int x0, x1, y0, y1; };
-    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels];
+    struct PipeFrame { bool valid = false; int ring = 0, tx = 0, crows = 0, ccols = 0; Win C[kMaxLevels]; double bytes[kMaxLevels], bytes_run[kMaxLevels];
                        int nrect[kMaxLevels]; BlockRect rect[kMaxLevels][kMaxRects];        // LevelLaunch::rect of each level
                        uint32_t need_bits[kMaxLevels][kNeedWords]; int need_n[kMaxLevels] = {};    // LevelLaunch::need_bits of the upper levels (need_n 0: none)
                        const uint64_t* table_args = nullptr; int table_n = 0; };            // level 0 only, valid during render_frame
@@ -264,16 +277,17 @@ private:
     std::thread worker_;
 
     // profile
-    struct ProfRec { int id; hipEvent_t a, b; double bytes; };
+    struct ProfRec { int id; hipEvent_t a, b; double bytes, bytes_run; };
     int prof_mode_ = 0; bool prof_on_ = false;
     unsigned prof_tick_[K_COUNT]{};
     std::vector<ProfRec> prof_pending_;
     std::vector<hipEvent_t> ev_pool_;
-    double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{};
+    double prof_ms_[K_COUNT]{}; long long prof_n_[K_COUNT]{}; double prof_bytes_[K_COUNT]{}, prof_bytes_run_[K_COUNT]{};
     ProfRec prof_cur_{};
     SectionRec sections_[T_COUNT];
     std::mutex timer_mu_;
     long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0, n_with_pixels_ = 0;
+    long long feed_seq_ = 0; std::vector<long long> render_log_;
     double px_level0_exact_ = 0;                    // PF_CULL_EXACT_STAT (diagnostics)
     double px_level0_ = 0, px_owned_ = 0;           // level-0 pixels computed (with halo) / tile pixels owned, over the frames rendered
 };

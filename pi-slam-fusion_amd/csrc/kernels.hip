@@ -19,7 +19,17 @@
 #include <cstdlib>
 #include <type_traits>
 
+// PF_EXPERIMENTS=1 (a second library, libpifusion_exp.so: tests/test_gpu_variants.py and the A/B tools load it through PF_LIB) also
+// compiles the forms of the level kernel that were built, measured and NOT adopted -- the wave-specialised rolling strips (strips.inc),
+// the LDS-staged source patch (PATCH), 64x28 and 64x64 blocks, the fetch/finish row loops of rounds 2-4 (PF_A_ILP), the stamped
+// instantiations and the timing-only ablation switches.  The product library carries the product instantiations only.
+#ifndef PF_EXPERIMENTS
+#define PF_EXPERIMENTS 0
+#endif
+
 namespace pf {
+
+constexpr bool kExp = PF_EXPERIMENTS != 0;
 
 // ---------------------------------------------------------------- helpers
 // border maps, saturate_cast<short> and the warp's source addressing: warp_index.hpp (shared with the host-side check)
@@ -360,7 +370,16 @@ struct LevelArgs {
     int nbx, nby;                 // block grid (k_strips: strips x segments)
     int ablate;                   // diagnostics only (PF_ABLATE): bit0 skip A math, bit1 skip H/B, bit2 skip U/D
     int seg;                      // k_strips: rows of a strip segment
+    unsigned inv_nbx;             // ceil(2^32 / nbx): block id -> (bx, by) by one multiply (a scalar division is ~20 dependent instructions, twice per workgroup)
+    int pad_;
 };
+// by = b / nbx by one multiply: with inv = ceil(2^32 / nbx), floor(b * inv / 2^32) = floor(b / nbx) while b * (inv * nbx - 2^32) < 2^32, which
+// nblk * nbx < 2^32 guarantees (level_inv_nbx); inv_nbx == 0: the division itself
+__device__ __forceinline__ void block_xy(const LevelArgs& g, int b, int& bx, int& by)
+{
+    if (g.inv_nbx) by = (int)__umulhi((unsigned)b, g.inv_nbx); else by = b / g.nbx;
+    bx = b - by * g.nbx;
+}
 
 // 1/d exactly as the compiler's IEEE fp64 division computes it when no operand scaling is needed
 // (v_div_scale_f64 and v_div_fixup_f64 are identities for 2^-500 < |d| < 2^500, v_div_fmas_f64 is a plain
@@ -499,6 +518,35 @@ __device__ __forceinline__ WarpTaps warp_fetch(const uint8_t* __restrict__ src, 
     return warp_fetch_pre<WA>(src, a, col, col.m0xb + a.M[1] * y + a.M[2], col.m3xb + a.M[4] * y + a.M[5], col.m6xb + a.M[7] * y + a.M[8]);
 }
 
+// The bilinear sum of a pixel whose four taps lie strictly inside the frame (tap_is_fast): (lo, hi) pixels of the two 8-byte row loads,
+// fractions fx, fy in 1/32 px, weight w -- remapBilinear's float form, evaluated left to right without contraction.
+template <bool F32>
+__device__ __forceinline__ PxT<F32> warp_finish_fast(uint32_t lo0, uint32_t hiw0, uint32_t lo1, uint32_t hiw1, int fxi, int fyi, float w, int cn)
+{
+    PxT<F32> o;
+    o.w = w;
+    const float fx = (float)fxi * (1.f / 32), fy = (float)fyi * (1.f / 32);
+    const float c0 = (1.f - fy) * (1.f - fx), c1 = (1.f - fy) * fx, c2 = fy * (1.f - fx), c3 = fy * fx;
+    const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;      // v_perm_b32: bytes cn..cn+3 of the 8
+    const uint32_t hi0 = __builtin_amdgcn_perm(hiw0, lo0, hisel), hi1 = __builtin_amdgcn_perm(hiw1, lo1, hisel);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v0 = (float)((lo0 >> (8 * k)) & 0xff), v1 = (float)((hi0 >> (8 * k)) & 0xff);
+        float v2 = (float)((lo1 >> (8 * k)) & 0xff), v3 = (float)((hi1 >> (8 * k)) & 0xff);
+        if constexpr (F32) {
+            const float s = (float)(1. / 255.);
+            v0 = v0 * s; v1 = v1 * s; v2 = v2 * s; v3 = v3 * s;
+            o.c[k] = v0 * c0 + v1 * c1 + v2 * c2 + v3 * c3;
+        } else {
+            // every product and partial sum is a multiple of 2^-10 below 2^8: exact in fp32 whatever the association, fused or not
+            const float tt = __builtin_fmaf(v3, c3, __builtin_fmaf(v2, c2, __builtin_fmaf(v1, c1, v0 * c0)));
+            o.c[k] = (short)sat_short(__float2int_rn(tt));
+        }
+    }
+    if constexpr (!F32) o.pad = 0;
+    return o;
+}
+
 template <bool F32>
 __device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
 {
@@ -576,6 +624,29 @@ __device__ __forceinline__ PxT<F32> warp_finish(const WarpTaps& t, int cn)
     }
     if constexpr (!F32) o.pad = 0;
     return o;
+}
+
+typedef uint32_t park8 __attribute__((ext_vector_type(2), aligned(8)));      // what stage A parks in a pixel's LDS slot: fractions, weight
+typedef uint32_t park4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// Does the canvas rectangle [x0, x0 + w) x [y0, y0 + h) map strictly inside the frame -- every pixel's four bilinear taps and its nearest
+// pixel inside it, not on the last two rows (tap_is_fast), coordinates in the tame range (warp_fetch_pre)?  Decided once per workgroup, the
+// same in every wave: lane l evaluates corner l & 3 exactly as the pixel there is evaluated.  W is affine, so one sign at the four corners is
+// one sign on the rectangle, where the map is then projective and takes it to the convex quadrilateral of the corners' images; a
+// quadrilateral whose corners keep ONE pixel of margin from the frame's fast region holds every pixel's computed coordinate (which differs from
+// its exact image by rounding only: below 1e-8 px for frames of at most 32767 px, a.plain).
+__device__ __forceinline__ bool block_maps_inside(const FusedWarp& a, int x0, int y0, int w, int h)
+{
+    const int lane = threadIdx.x & 3;
+    const int x = x0 + ((lane & 1) ? w - 1 : 0), y = y0 + ((lane & 2) ? h - 1 : 0);
+    const WarpCol col = warp_col(a, x);
+    const double X0 = col.m0xb + a.M[1] * y + a.M[2], Y0 = col.m3xb + a.M[4] * y + a.M[5], W0 = col.m6xb + a.M[7] * y + a.M[8];
+    const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
+    const double Wn = rcp_mid_range(W);
+    const double px = xn * Wn, py = yn * Wn;
+    const bool ok = px >= 1.0 && px <= (double)(a.scols - 3) && py >= 1.0 && py <= (double)(a.srows - 4) && fabs(W) > 0x1p-400;
+    const unsigned long long pos = __builtin_amdgcn_ballot_w64(W > 0.0);
+    return __builtin_amdgcn_ballot_w64(!ok) == 0 && (pos == 0 || pos == __builtin_amdgcn_ballot_w64(true));
 }
 
 // one canvas pixel of the warp: image (LINEAR, REFLECT) + weight (NEAREST, CONSTANT 0)
@@ -739,7 +810,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
         for (int idx = rb * LAW + tid; idx < LAH * LAW; idx += LNT) {
             int y = ay0 + r, x = ax0 + c;
             if (!inner) { y = border_reflect101(y, g.rows); x = border_reflect101(x, g.cols); }
-            if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
+            if (kExp && (g.ablate & 1)) { Px z{}; z.w = (float)(x + y); (&A[0][0])[idx] = z; } else
             (&A[0][0])[idx] = warp_pixel<F32>(src, wa, warp_col(wa, x), y);
             c += LNT % LAW; r += LNT / LAW;
             if (c >= LAW) { c -= LAW; r++; }
@@ -748,7 +819,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
         stage_from_hbm<F32, LAH, LNT>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid, rb * LAW);
     }
     lds_barrier();
-    if (g.ablate & 2) return;
+    if (kExp && (g.ablate & 2)) return;
     // stored weights of the D pixels: in flight during H / B / U (the barriers below wait for LDS only)
 #pragma unroll
     for (int it = 0; it < ND; it++) {
@@ -812,7 +883,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
         }
     }
     lds_barrier();
-    if (g.ablate & 4) return;
+    if (kExp && (g.ablate & 4)) return;
     // ---- U: horizontal pyrUp of the B rows into LDS (re-uses Ht, dead after B)
     Hx (*U)[LBW] = reinterpret_cast<Hx (*)[LBW]>(&Ht[0][0]);
     static_assert(sizeof(Hx) * LQH * LBW <= sizeof(Hx) * LAH * LQW, "U must fit in Ht");
@@ -945,14 +1016,14 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     static_assert(LBH != 32 || !PATCH || sizeof(A) + sizeof(tail) <= 64 * 1280, "LDS budget (64x32 blocks with a source patch: two per CU)");
     static_assert(LBH != 64 || sizeof(A) + sizeof(tail) <= (F32 ? 128 : 64) * 1280, "LDS budget (64x64 blocks of 1024 threads: int16 two per CU, fp32 one)");
 
-    const int bx = b % g.nbx, by = b / g.nbx;
+    int bx, by; block_xy(g, b, bx, by);
     const int x0 = g.cx0 + bx * LBW, y0 = g.cy0 + by * LBH;
     const int ax0 = x0 - 4, ay0 = y0 - 4;
     const int nrows = g.rows >> 1, ncols = g.cols >> 1;         // level i+1 extent
     const int bx0 = (x0 >> 1) - 1, by0 = (y0 >> 1) - 1;
     const int tid = threadIdx.x;
     const int sh = 8 - g.level, ts = kElePixels >> g.level;
-    if ((g.ablate & 512) && !FROM_WARP) __builtin_amdgcn_s_setprio(2);      // A/B: upper-level (latency-bound) workgroups first
+    if (kExp && (g.ablate & 512) && !FROM_WARP) __builtin_amdgcn_s_setprio(2);      // A/B: upper-level (latency-bound) workgroups first
 
     // this thread's output quad and its tile-table entry (a quad never straddles tiles)
     const int qx = tid & 31, qy = tid >> 5;
@@ -1104,7 +1175,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     const int rb = r + RS;
                     const bool hasb = rb < LAH;
                     const int y = row_of(r), yb = row_of(hasb ? rb : r);
-                    if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
+                    if (kExp && (g.ablate & 1)) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
                     const Cd qa = coords(y), qb = coords(yb);
                     if (__builtin_amdgcn_ballot_w64(!(qa.ok && qb.ok)) == 0) {
                         Aat(r, c) = fast(qa);
@@ -1114,6 +1185,57 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                         Aat(r, c) = warp_pixel<F32>(src, wa, col, y);
                         if (hasb) Aat(rb, c) = warp_pixel<F32>(src, wa, col, yb);
                     }
+                }
+            }
+        } else
+        if (ILP == 0 && WA && inner && wa.plain && block_maps_inside(wa, ax0, ay0, LAW, LAH)) {
+            // ---- the product's stage A for a block whose staged rectangle maps strictly inside the frame (nine in ten of the blocks that run
+            // in the steady state): no pixel needs the range test, the border forms or the frame test, so the row loop is straight-line code.
+            // A thread keeps one column and walks down it ONCE: per row the coordinates, the weight and the two row loads -- issued at once,
+            // consumed last; what the bilinear sum needs later (the 1/32-px fractions and the weight) is PARKED in the pixel's own LDS slot,
+            // which is idle until the finished pixel is written there (the same thread reads what it wrote: no barrier).  Then every row's
+            // bilinear sum.  All 2 x 6 loads of a thread are in flight while it computes the coordinates of its later rows, and a wave
+            // waits for memory once per block instead of once per step (rounds 2-4: fetch, fetch, fetch | finish, finish, finish per step;
+            // the straight-line form of that loop was +22 % per wave but needed 94-123 VGPRs for the parked state, r02).
+            if (r0 < RS) {
+                constexpr int NR = (LAH + RS - 1) / RS;
+                typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
+                using p2 = typename std::conditional<F32, park8, park4>::type;       // an int16 slot is 12 bytes
+                const WarpCol col = warp_col(wa, ax0 + c);
+                const int cn = wa.cn, sstep = wa.sstep;
+                u2 b0[NR], b1[NR];
+                // the last pass holds rows for the first LAH - (NR - 1) * RS threads-rows only: a wave none of whose lanes has one skips it
+                const bool last = r0 + (NR - 1) * RS < LAH;
+                const bool any_last = __builtin_amdgcn_ballot_w64(last) != 0;
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    if (k == NR - 1 && !any_last) break;
+                    const bool has = k < NR - 1 || last;
+                    const int r = has ? r0 + k * RS : r0;
+                    const int y = ay0 + r;
+                    const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
+                    const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
+                    const double Wn = rcp_mid_range(W);
+                    const double pxn = xn * Wn, pyn = yn * Wn;
+                    constexpr double kMagic = 6755399441055744.0;
+                    const int Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
+                    const int Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
+                    // 32 * p is exact, so the fused form rounds once, exactly as p * 32 + magic does
+                    const int X = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pxn, 32., kMagic));
+                    const int Y = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pyn, 32., kMagic));
+                    const float wgt = radial_weight(wa, Xn, Yn);
+                    const uint32_t off0 = (uint32_t)(__mul24(Y >> 5, sstep) + __mul24(cn, X >> 5));
+                    if (has) *reinterpret_cast<p2*>(&Aat(r, c)) = p2{ (uint32_t)((X & 31) | (Y & 31) << 5), __float_as_uint(wgt) };
+                    b0[k] = PF_LOAD_SRC((const u2*)(src + off0)); b1[k] = PF_LOAD_SRC((const u2*)(src + off0 + (uint32_t)sstep));
+                }
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    if (k == NR - 1 && !any_last) break;
+                    const bool has = k < NR - 1 || last;
+                    if (!has) continue;
+                    const int r = r0 + k * RS;
+                    const p2 pk = *reinterpret_cast<const p2*>(&Aat(r, c));
+                    Aat(r, c) = warp_finish_fast<F32>(b0[k].x, b0[k].y, b1[k].x, b1[k].y, (int)(pk.x & 31u), (int)(pk.x >> 5), __uint_as_float(pk.y), cn);
                 }
             }
         } else
@@ -1127,7 +1249,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     const int rb = r + RS, rc = r + 2 * RS;
                     const bool hasb = rb < LAH, hasc = rc < LAH;
                     const int y = row_of(r), yb = row_of(hasb ? rb : r), yc = row_of(hasc ? rc : r);
-                    if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; if (hasc) Aat(rc, c) = z; continue; }
+                    if (kExp && (g.ablate & 1)) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; if (hasc) Aat(rc, c) = z; continue; }
                     const WarpTaps ta = warp_fetch<WA>(src, wa, col, y);
                     const WarpTaps tb = warp_fetch<WA>(src, wa, col, yb);
                     if (__builtin_amdgcn_ballot_w64(hasc) != 0) {
@@ -1150,7 +1272,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
                     if (near101) { y = border_reflect101_near(y, g.rows); yb = border_reflect101_near(yb, g.rows); }
                     else { y = border_reflect101(y, g.rows); yb = border_reflect101(yb, g.rows); }
                 }
-                if (g.ablate & 1) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
+                if (kExp && (g.ablate & 1)) { Px z{}; z.w = (float)(x + y); Aat(r, c) = z; if (hasb) Aat(rb, c) = z; continue; }
                 const WarpTaps ta = warp_fetch<WA>(src, wa, col, y);
                 if (__builtin_amdgcn_ballot_w64(hasb) != 0) {
                     const WarpTaps tb = warp_fetch<WA>(src, wa, col, hasb ? yb : y);
@@ -1166,8 +1288,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     if (STAMP) phase_stamp(stamps, 1);
     lds_barrier();
     if (STAMP) phase_stamp(stamps, 2);
-    if (g.ablate & 2) return;
-    if (g.ablate & 256) __builtin_amdgcn_s_setprio(2);           // A/B: the short memory-bound stages ahead of other workgroups' warp
+    if (kExp && (g.ablate & 2)) return;
+    if (kExp && (g.ablate & 256)) __builtin_amdgcn_s_setprio(2);           // A/B: the short memory-bound stages ahead of other workgroups' warp
 
     // stored weights of the quad: in flight during stage B
     float dwv[2][2] = { { -1.f, -1.f }, { -1.f, -1.f } };           // fresh tile: every weight (>= 0) wins
@@ -1303,7 +1425,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     if (STAMP) phase_stamp(stamps, 3);
     lds_barrier();
     if (STAMP) phase_stamp(stamps, 4);
-    if (g.ablate & 4) return;
+    if (kExp && (g.ablate & 4)) return;
 
     // ---- D: 2x2 quad, Laplacian + max-weight select
     if (!ent) return;
@@ -1315,10 +1437,12 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
     const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
     const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
+#ifdef PF_COUNT_WINS        // tools/count_wins.py (a build of its own: tools/build_variant.sh wins -DPF_EXPERIMENTS=1 -DPF_COUNT_WINS=1): two atomics per thread distort the stamps
     if constexpr (STAMP) {
         atomicAdd(&g_select_seen[g.level], (unsigned long long)(1 + (int)in01 + (int)in10 + (int)(in10 && in01)));
         atomicAdd(&g_select_won[g.level], (unsigned long long)((int)s00 + (int)s01 + (int)s10 + (int)s11));
     }
+#endif
     if (!(s00 || s01 || s10 || s11)) return;
     const int sy = dy0 >> 1, sx = dx0 >> 1;
     int syn = sy + 1; if (syn >= nrows) syn = nrows - 1;
@@ -1444,66 +1568,122 @@ __global__ __launch_bounds__(LNT, 4) void k_level3(LevelOffsets lay, LevelArgs g
 // GW_i, written by that frame's level i-1 job one launch earlier -- so the small upper levels fill the
 // chip alongside level 0 inside ONE grid, with no stream/queue multiplexing involved.  Jobs are laid out
 // level 0 first (the short upper-level blocks fill the tail); each starts at a block id that is a multiple of 8.
+// What a workgroup needs before its first pixel comes first -- 20 dwords, loaded in one round (k_levels); the rest is read where it is used.
 struct LevelJob {
-    LevelOffsets lay;
-    LevelArgs    g;
-    const void*  gw_in;
-    void*        gw_out;
-    const uint64_t* table;     // the tile table of the job's frame (device memory)
+    LevelArgs    g;            // 16 dwords
     int first;                 // first block id
     int from_warp;             // level 0: stage A is the warp of the launch's frame
     int nrect;                 // see LevelLaunch::rect
-    BlockRect rect[kMaxRectsUpper];   // job 0 of a launch: LevelBatch::rect0 instead (up to kMaxRects)
     int bits_off;              // first word of the job's need bitmap in LevelBatch::need_bits, -1: none (the rectangles decide)
+    LevelOffsets lay;
+    const void*  gw_in;
+    void*        gw_out;
+    const uint64_t* table;     // the tile table of the job's frame (device memory)
+    BlockRect rect[kMaxRectsUpper];   // job 0 of a launch: LevelBatch::rect0 instead (up to kMaxRects)
 };
+static_assert(sizeof(LevelArgs) == 64 && offsetof(LevelJob, first) == 64 && offsetof(LevelJob, lay) == 80 && sizeof(LevelJob) == 152, "LevelJob layout (k_levels loads its first 20 dwords by hand)");
 // job[k].first, k >= 1: block offset among the upper-level jobs.  tab0: the tile table of job 0's frame when it travels
 // in the kernel arguments (tab0_n entries; 0: job 0 reads job[0].table like the others)
 // need_r0 (job 0, tile table in the arguments): instead of the need rectangles, a level-0 block decides for itself whether anything
 // rendered depends on it -- whether a cell that is rendered (entry != 0, cell flag clear) lies within need_r0 = 3 * 2^L - 2
 // pixels of it, the reach of the pyramid (`need` recursion of FusionMap::render_frame: pyrDown reads [2p-2, 2p+2], pyrUp +-1).
 // Exact at cell granularity, where eight bounding boxes are not (profiles/r04_ab.md).
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels]; BlockRect rect0[kMaxRects]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
+// kernel-argument words by explicit scalar loads (s_load_dwordx16 / x4 through the constant address space), issued together
+#define PF_CONST __attribute__((address_space(4)))
+typedef uint32_t su16 __attribute__((ext_vector_type(16)));
+typedef uint32_t su8 __attribute__((ext_vector_type(8)));
+typedef uint32_t su4 __attribute__((ext_vector_type(4)));
+typedef uint32_t su2 __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void load_words(const char PF_CONST* p, uint32_t (&w)[N])
+{
+    static_assert(N % 4 == 0, "whole 16-byte groups");
+    int i = 0;
+#pragma unroll
+    for (; i + 16 <= N; i += 16) { const su16 v = *(const su16 PF_CONST*)(p + 4 * i); for (int k = 0; k < 16; k++) w[i + k] = v[k]; }
+#pragma unroll
+    for (; i + 4 <= N; i += 4) { const su4 v = *(const su4 PF_CONST*)(p + 4 * i); for (int k = 0; k < 4; k++) w[i + k] = v[k]; }
+}
+
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels - 1]; BlockRect rect0[kMaxRects]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 2 * sizeof(void*) <= 4096, "kernel arguments of k_levels: 4 KB");
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
-__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ? 8 : 6) : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
+__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 || ILP == 0)) ? 8 : 6) : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
     // when there is one) or to the upper-level jobs: last in the grid by default, or (PF_INTERLEAVE_JOBS, diagnostics)
     // spread evenly between the first job's groups.
+    unsigned long long t_entry = 0;
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_entry) :: "memory");      // stamped build: kernel entry
+    // The prologue is a chain of scalar loads from the kernel-argument segment, and a workgroup holds its slot (80 VGPRs x 512 threads,
+    // 52 KB of LDS) while it waits for them: written as `B.job[j].field` wherever a field is needed, the compiler emits about ten
+    // DEPENDENT load / s_waitcnt rounds before the first pixel (measured with the stamped build, profiles/r05_ab.md: 3600 cycles median
+    // of a level-0 workgroup's 24 700).  So: ONE round for everything whose address does not depend on data -- the header, every job's first
+    // block, job 0 whole (speculative: three in four workgroups are level-0 ones) -- then at most one more for an upper-level job.
+    const char PF_CONST* const ka = (const char PF_CONST*)__builtin_amdgcn_kernarg_segment_ptr();
+    const LevelBatch PF_CONST& B = *(const LevelBatch PF_CONST*)ka;          // `batch` as it lies in the kernel-argument segment: every access a scalar load
+    (void)batch;
+    static_assert(offsetof(LevelBatch, job) == 32, "the header is one s_load_dwordx8");
+    const su8 hdr = *(const su8 PF_CONST*)ka;                                // njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0
+    su16 ja = *(const su16 PF_CONST*)(ka + 32); su4 jb = *(const su4 PF_CONST*)(ka + 32 + 64);      // job 0: LevelArgs | first, from_warp, nrect, bits_off
+    int first[kMaxLevels];
+#pragma unroll
+    for (int k = 1; k < kMaxLevels - 1; k++) first[k] = *(const int PF_CONST*)(ka + offsetof(LevelBatch, job) + k * sizeof(LevelJob) + offsetof(LevelJob, first));
+    // (the empty statements pin the loads here: left alone, the compiler sinks each one to its first use and the chain is back)
+    asm volatile("" :: "s"(hdr), "s"(ja), "s"(jb));
+    asm volatile("" :: "s"(first[1]), "s"(first[2]), "s"(first[3]), "s"(first[4]), "s"(first[5]), "s"(first[6]), "s"(first[7]));
+    static_assert(kMaxLevels == 9, "first[1..7]: a launch carries at most kMaxLevels - 1 level jobs");
+    const int njobs = (int)hdr[0], ug = (int)hdr[1], tg = (int)hdr[2], seq = (int)hdr[3], tab0_n = (int)hdr[4], rect_runs = (int)hdr[5], need_r0 = (int)hdr[6];
     const int g = (int)blockIdx.x >> 3, lane8 = (int)blockIdx.x & 7;
-    const int ug = batch.upper_groups, tg = batch.total_groups;
-    int u0 = (int)(((long)g * ug) / tg), u1 = (int)(((long)(g + 1) * ug) / tg);
-    if (batch.sequential == 1) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // upper levels last (default)
-    if (batch.sequential == 2) { u0 = g < ug ? g : ug; u1 = g < ug ? g + 1 : ug; }                             // upper levels first (PF_UPPER_FIRST)
+    int u0, u1;
+    if (!kExp || seq == 1) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // upper levels last (default; the product's only order)
+    else if (seq == 2) { u0 = g < ug ? g : ug; u1 = g < ug ? g + 1 : ug; }                          // upper levels first (PF_UPPER_FIRST)
+    else { u0 = (int)(((long)g * ug) / tg); u1 = (int)(((long)(g + 1) * ug) / tg); }                 // dealt between the first job's groups (PF_INTERLEAVE_JOBS)
     int j = 0, b;
     if (u1 > u0) {                                            // an upper-level group
         b = u0 * 8 + lane8;
         j = 1;
-        for (int k = 2; k < batch.njobs; k++) if (b >= batch.job[k].first) j = k;
-        b -= batch.job[j].first;
+        int fj = first[1];
+#pragma unroll
+        for (int k = 2; k < kMaxLevels - 1; k++) if (k < njobs && b >= first[k]) { j = k; fj = first[k]; }
+        b -= fj;
+        j = __builtin_amdgcn_readfirstlane(j); b = __builtin_amdgcn_readfirstlane(b);      // uniform by construction: keep the job in scalar registers
+        const char PF_CONST* jp = ka + offsetof(LevelBatch, job) + j * sizeof(LevelJob);
+        ja = *(const su16 PF_CONST*)jp; jb = *(const su4 PF_CONST*)(jp + 64);
     } else
         b = (g - u0) * 8 + lane8;
-    const LevelJob& J = batch.job[j];
+    // the job: its first 20 dwords from the registers just loaded, the rest (level offsets, GW buffers, table, rectangles) read from the
+    // kernel arguments where it is used
+    struct JobHead { LevelArgs g; int first, from_warp, nrect, bits_off; } J;
+    {
+        uint32_t jw[20];
+#pragma unroll
+        for (int k = 0; k < 16; k++) jw[k] = ja[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) jw[16 + k] = jb[k];
+        __builtin_memcpy(&J, jw, sizeof J);
+    }
+    const LevelJob PF_CONST& Jc = B.job[j];
     const int nblk = J.g.nbx * J.g.nby;
     if (b >= nblk) return;                                     // padding up to the next multiple of 8
     // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
     // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
-    const int bb = batch.rect_runs >= 3 ? xcd_chunks(b, nblk, 1 << (batch.rect_runs - 1)) :        // A/B: runs of 4 / 8 / 16 blocks per XCD
-                   ((J.nrect && !batch.rect_runs) || batch.rect_runs == 2) ? b : xcd_order(b, nblk);
+    const int rr = kExp ? rect_runs : 0;                  // PF_RECT_ORDER (A/B): 1 XCD runs even with rectangles, 2 round robin always, >= 3 runs of 4 / 8 / 16 blocks
+    const int bb = rr >= 3 ? xcd_chunks(b, nblk, 1 << (rr - 1)) : ((J.nrect && !rr) || rr == 2) ? b : xcd_order(b, nblk);
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
     // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
     const uint64_t* tab0 = nullptr;
-    if (j == 0 && batch.tab0_n) {
+    if (j == 0 && tab0_n) {
         tab0 = (const uint64_t*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LevelBatch, tab0));
-        if (b == 0) for (int i = threadIdx.x; i < batch.tab0_n; i += LNT) const_cast<uint64_t*>(J.table)[i] = tab0[i];
+        if (b == 0) for (int i = threadIdx.x; i < tab0_n; i += LNT) const_cast<uint64_t*>(Jc.table)[i] = tab0[i];
     }
-    if (j == 0 && tab0 && batch.need_r0 && J.nrect) {
+    if (j == 0 && tab0 && need_r0 && J.nrect) {
         // job 0: is a rendered cell within the pyramid's reach of this block?  Tile by tile: the cells of the tile inside the reach
         // as a 16-bit mask against the entry's culled cells
-        const int bx = bb % J.g.nbx, by = bb / J.g.nbx, r0 = batch.need_r0;
+        int bx, by; block_xy(J.g, bb, bx, by); const int r0 = need_r0;
         int x0 = J.g.cx0 + bx * LBW - r0, x1 = J.g.cx0 + bx * LBW + LBW - 1 + r0, y0 = J.g.cy0 + by * LBH - r0, y1 = J.g.cy0 + by * LBH + LBH - 1 + r0;
         x0 = x0 > 0 ? x0 : 0; y0 = y0 > 0 ? y0 : 0; x1 = x1 < J.g.cols - 1 ? x1 : J.g.cols - 1; y1 = y1 < J.g.rows - 1 ? y1 : J.g.rows - 1;
         // need_r0 <= 96: the reach spans two tiles a side at most -- four entries, the cells of each inside the reach as a 16-bit mask
@@ -1513,28 +1693,35 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
         auto rows = [](int a, int b) { return (0xffffu << (4 * a)) & (0xffffu >> (4 * (3 - b))); };
         const unsigned mx0 = cols(cx0 & 3, tx1 > tx0 ? 3 : cx1 & 3), mx1 = cols(tx1 > tx0 ? 0 : cx0 & 3, cx1 & 3);
         const unsigned my0 = rows(cy0 & 3, ty1 > ty0 ? 3 : cy1 & 3), my1 = rows(ty1 > ty0 ? 0 : cy0 & 3, cy1 & 3);
-        const uint64_t e00 = tab0[ty0 * J.g.tiles_x + tx0], e01 = tab0[ty0 * J.g.tiles_x + tx1];
-        const uint64_t e10 = tab0[ty1 * J.g.tiles_x + tx0], e11 = tab0[ty1 * J.g.tiles_x + tx1];
+        const uint64_t PF_CONST* t0c = (const uint64_t PF_CONST*)(ka + offsetof(LevelBatch, tab0));
+        const uint64_t e00 = t0c[ty0 * J.g.tiles_x + tx0], e01 = t0c[ty0 * J.g.tiles_x + tx1];
+        const uint64_t e10 = t0c[ty1 * J.g.tiles_x + tx0], e11 = t0c[ty1 * J.g.tiles_x + tx1];
+        asm volatile("" :: "s"(e00), "s"(e01), "s"(e10), "s"(e11));               // one round of four loads
         auto rendered = [](uint64_t e, unsigned m) { return (int)(e != 0 && (~((uint32_t)(e >> 32) >> 16) & m) != 0); };
         const bool hit = (rendered(e00, my0 & mx0) | rendered(e01, my0 & mx1) | rendered(e10, my1 & mx0) | rendered(e11, my1 & mx1)) != 0;
         if (!hit) return;
     } else
     if (J.bits_off >= 0) {                                     // an upper-level job with its need bitmap in the kernel arguments
-        if (!((batch.need_bits[J.bits_off + (bb >> 5)] >> (bb & 31)) & 1u)) return;
+        if (!((B.need_bits[J.bits_off + (bb >> 5)] >> (bb & 31)) & 1u)) return;
     } else
     if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
-        const int bx = bb % J.g.nbx, by = bb / J.g.nbx;
+        int bx, by; block_xy(J.g, bb, bx, by);
         bool hit = false;
         for (int k = 0; k < J.nrect; k++) {
-            const BlockRect r = j == 0 ? batch.rect0[k] : J.rect[k < kMaxRectsUpper ? k : 0];
+            // (read where they lie in the kernel arguments: indexing J.rect would put the job on the stack)
+            const char PF_CONST* rp = j == 0 ? ka + offsetof(LevelBatch, rect0) + k * sizeof(BlockRect)
+                                             : ka + offsetof(LevelBatch, job) + j * sizeof(LevelJob) + offsetof(LevelJob, rect) + (k < kMaxRectsUpper ? k : 0) * sizeof(BlockRect);
+            const uint64_t rw = *(const uint64_t PF_CONST*)rp;
+            BlockRect r; r.x0 = (short)(rw & 0xffff); r.y0 = (short)((rw >> 16) & 0xffff); r.x1 = (short)((rw >> 32) & 0xffff); r.y1 = (short)(rw >> 48);
             hit = hit || (bx >= r.x0 && bx < r.x1 && by >= r.y0 && by < r.y1);
         }
         if (!hit) return;
     }
     unsigned long long* st = nullptr;
-    if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
-    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH, WA>(J.from_warp != 0, J.lay, J.g, wa, src, (const PxT<F32>*)J.gw_in, (PxT<F32>*)J.gw_out,
-                                                       J.table, bb, st, tab0);
+    if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j | t_entry << 4; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
+    const LevelOffsets lay{ Jc.lay.lap_off, Jc.lay.w_off, Jc.lay.top_lap_off, Jc.lay.top_w_off };
+    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH, WA>(J.from_warp != 0, lay, J.g, wa, src, (const PxT<F32>*)Jc.gw_in, (PxT<F32>*)Jc.gw_out,
+                                                       Jc.table, bb, st, tab0);
 }
 
 // radial_weight() forms dis = fma(dx, dx, dy * dy): one rounding, equal to the reference's RN(RN(dy^2) + RN(dx^2)) only while
@@ -1542,7 +1729,9 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && ILP == 2) ?
 // weight from the plane instead (the reference's own weightImage, built by launch_weight32).
 static bool radial_weight_exact(const WarpArgs& wa) { return wa.srows < 8192 && wa.scols < 8192; }
 
+#if PF_EXPERIMENTS
 #include "strips.inc"
+#endif
 
 // FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
 static int plain_homography(const WarpArgs& wa)
@@ -1553,6 +1742,7 @@ static int plain_homography(const WarpArgs& wa)
     return 1;
 }
 
+#if PF_EXPERIMENTS
 // Can this frame's level 0 run with LDS-staged source patches (k_levels<..., PATCH>)?  Needs, over the whole canvas plus
 // the 4-pixel halo of the blocks: W of one sign and every source coordinate far inside the int range (then no pixel
 // needs warp_fetch_pre's range test), and a patch -- the source rectangle a 71x39 block of canvas pixels maps into,
@@ -1611,6 +1801,14 @@ static bool patch_plan(const WarpArgs& wa, int crows, int ccols, int block_rows,
     return true;
 }
 
+#endif   // PF_EXPERIMENTS
+
+static unsigned level_inv_nbx(int nbx, int nby)          // LevelArgs::inv_nbx, see block_xy
+{
+    if (nbx <= 1 || (unsigned long long)nbx * nby * nbx >= 0x100000000ull) return 0;
+    return (unsigned)((0x100000000ull + (unsigned)nbx - 1) / (unsigned)nbx);
+}
+
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
@@ -1625,11 +1823,12 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     // 3 workgroups per CU, 56 VGPRs / 38.1 KB int16 -> 4).  Measured on MI355X (cfg-A) k_level3 is
     // the faster one for both pyramid types; shape 2 (pf_options.fused = 2) or PF_KLEVEL=4 selects k_level.
     static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
-    static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
+    static const int ablate = kExp && getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const bool use4 = force == 4 || (force != 3 && shape == 2);
     const int BH = use4 ? 16 : 32;
     const int LSTEPS = 1;     // rolling strips (k_level<..., LS>1>) measured slower on MI355X: kept at one block per workgroup
     g.nbx = (cx1 - cx0 + LBW - 1) / LBW; g.nby = (cy1 - cy0 + BH * LSTEPS - 1) / (BH * LSTEPS);
+    g.inv_nbx = level_inv_nbx(g.nbx, g.nby);
     g.ablate = ablate;
     if (g.nbx <= 0 || g.nby <= 0) return;
     dim3 grid(g.nbx * g.nby);
@@ -1655,7 +1854,7 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
 
 static unsigned long long* g_stamp_buf = nullptr;
 static int g_stamp_blocks = 0;
-constexpr int kStampBlocks = 1 << 16;
+[[maybe_unused]] constexpr int kStampBlocks = 1 << 16;
 
 // launches of the pipelined level kernel by form since the library was loaded (tests/test_gpu_variants.py asserts that the form a
 // switch asks for really ran): 0 block form, computed weight (default); 1 block form, weight plane gather; 2 LDS-staged source patch;
@@ -1663,6 +1862,7 @@ constexpr int kStampBlocks = 1 << 16;
 static long long g_form_counts[8] = {};
 void read_form_counts(long long out[8]) { for (int i = 0; i < 8; i++) out[i] = g_form_counts[i]; }
 
+#if PF_EXPERIMENTS
 // The wave-specialised rolling-strip form of the pipelined launch (strips.inc).  Returns false when this launch has to take
 // the block form (diagnostic builds, the gathered weight plane).
 static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
@@ -1743,10 +1943,12 @@ static bool launch_strips(hipStream_t s, const TileLayout& lay, const LevelLaunc
     return true;
 }
 
+#endif   // PF_EXPERIMENTS
+
 int level0_need_reach(const TileLayout& lay, int table_n, int nrect0)
 {
-    static const bool off = getenv("PF_NO_NEED_R0") != nullptr;                                 // A/B: the need rectangles for job 0 too
-    static const bool strips = getenv("PF_STRIPS") && atoi(getenv("PF_STRIPS")) != 0;             // the strip form keeps the rectangles
+    static const bool off = kExp && getenv("PF_NO_NEED_R0") != nullptr;                                 // A/B: the need rectangles for job 0 too
+    static const bool strips = kExp && getenv("PF_STRIPS") && atoi(getenv("PF_STRIPS")) != 0;             // the strip form keeps the rectangles
     if (off || strips || table_n <= 0 || table_n > kArgTable || nrect0 <= 0 || level_block_rows(lay.f32 != 0) != 32) return 0;
     const int r0 = 3 * (1 << (lay.nlev - 1)) - 2;
     return r0 <= 96 ? r0 : 0;                                     // beyond five bands the reach spans more than two tiles: the rectangles
@@ -1754,12 +1956,14 @@ int level0_need_reach(const TileLayout& lay, int table_n, int nrect0)
 
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src)
 {
+#if PF_EXPERIMENTS
     if (level_block_rows(lay.f32 != 0) == 32 && launch_strips(s, lay, jobs, njobs, wa, src)) return;
-    static const int ablate = getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
+#endif
+    static const int ablate = kExp && getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const int BH = level_block_rows(lay.f32 != 0);
     LevelBatch batch{};
     int first_blocks = 0, upper_blocks = 0, bits_words = 0;
-    static const bool use_bits = getenv("PF_NO_NEED_BITS") == nullptr;       // A/B: the rectangles for the upper levels
+    static const bool use_bits = !(kExp && getenv("PF_NO_NEED_BITS"));       // A/B: the rectangles for the upper levels
     for (int k = 0; k < njobs; k++) {
         const LevelLaunch& q = jobs[k];
         LevelJob& J = batch.job[batch.njobs];
@@ -1767,6 +1971,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         J.g.tiles_x = q.tiles_x; J.g.top_select = q.top_select; J.g.write_next = q.write_next; J.g.ablate = ablate;
         J.g.nbx = (q.cx1 - q.cx0 + LBW - 1) / LBW; J.g.nby = (q.cy1 - q.cy0 + BH - 1) / BH;
         if (J.g.nbx <= 0 || J.g.nby <= 0) continue;
+        J.g.inv_nbx = level_inv_nbx(J.g.nbx, J.g.nby);
         J.lay = LevelOffsets{ lay.lap_off[q.level], lay.w_off[q.level], lay.lap_off[q.level + 1], lay.w_off[q.level + 1] };
         J.gw_in = q.gw_in; J.gw_out = q.gw_out; J.table = q.table; J.from_warp = q.from_warp;
         // job 0 keeps its rectangles in LevelBatch::rect0 (up to kMaxRects), the others in their own (kMaxRectsUpper; more than that -- the
@@ -1802,11 +2007,14 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8;
     // measured on MI355X (tools/ab.sh, cfg-A fp32): upper levels dealt between the level-0 groups 156 us per launch, upper
     // levels last 151 us -- a latency-bound workgroup in a slot costs the level-0 phase more than the tail costs
-    static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
-    static const bool upper_first = getenv("PF_UPPER_FIRST") != nullptr;
-    batch.sequential = upper_first ? 2 : !interleave;
-    static const int rect_runs = getenv("PF_RECT_ORDER") ? atoi(getenv("PF_RECT_ORDER")) : 0;      // 1: XCD runs even with rectangles; 2: round robin always (A/B)
-    batch.rect_runs = rect_runs;
+    batch.sequential = 1;
+    if (kExp) {
+        static const bool interleave = getenv("PF_INTERLEAVE_JOBS") != nullptr;
+        static const bool upper_first = getenv("PF_UPPER_FIRST") != nullptr;
+        batch.sequential = upper_first ? 2 : !interleave;
+        static const int rect_runs = getenv("PF_RECT_ORDER") ? atoi(getenv("PF_RECT_ORDER")) : 0;      // 1: XCD runs even with rectangles; 2: round robin always (A/B)
+        batch.rect_runs = rect_runs;
+    }
     if (batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0) batch.need_r0 = level0_need_reach(lay, batch.tab0_n, batch.job[0].nrect);
     if (!batch.njobs) return;
     FusedWarp w{};
@@ -1815,14 +2023,25 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         w.total = frame_bytes(wa->srows, wa->scols, wa->sstep, wa->src_cn); w.wmap = wa->wmap;
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
         w.plain = plain_homography(*wa);
+        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
     }
-    static const bool stamp = getenv("PF_STAMP") != nullptr;
-    // warp rows a thread has in flight per step.  fp32: 3 (+1.2 % over 2, r02).  int16: 2 -- that form fits 64 VGPRs, so FOUR
-    // workgroups share a CU (38.6 KB of LDS each) instead of three: +3.2 % over 3 rows at three per CU (profiles/r03_ab.md)
-    static const int ilp_env = getenv("PF_A_ILP") ? atoi(getenv("PF_A_ILP")) : 0;
-    const int ilp = ilp_env > 0 ? ilp_env : (lay.f32 ? 3 : 2);
+    if (batch.tab0_n) g_form_counts[7]++;
+    // The radial weight is computed in the kernel (radial_weight; two gathers per warped pixel instead of three: fp32 +1.8 %, int16 +-0
+    // against the weight plane gather, profiles/r03_ab.md) unless the frame is too large for its exactness argument -- those frames, and
+    // PF_WEIGHT_PLANE=1 (tests), gather the reference's weightImage plane as fused = 0/2/3 do.
+    static const bool wplane_env = getenv("PF_WEIGHT_PLANE") != nullptr;
+    const bool wplane = wplane_env || (wa && !radial_weight_exact(*wa));
     unsigned long long* st = nullptr;
-    if (stamp) {
+    // Stage A of a level-0 block (level3_block): fp32 -- every row's coordinates, weight and row loads first, every bilinear sum last, the
+    // fractions and the weight parked in the pixel's own LDS slot meanwhile (ILP 0; blocks that do not map strictly inside
+    // the frame, and frames that gather the weight plane, walk two / three rows per step as before).  int16 -- two rows per step (ILP 2): that form
+    // fits 64 VGPRs, so four workgroups share a CU; the deferred form spills there and is 10 % slower.  Measured, same box, interleaved
+    // (profiles/r05_ab.md): fp32 +5 % over round 4's three rows per step once the prologue's scalar loads are batched, int16 +4 % from the
+    // prologue alone.
+#if PF_EXPERIMENTS
+    static const bool stamp = getenv("PF_STAMP") != nullptr;
+    static const int ilp_env = getenv("PF_A_ILP") ? atoi(getenv("PF_A_ILP")) : -1;       // 0: deferred finishes; 2 / 3: rows per step
+    if (stamp && BH == 32) {
         if (!g_stamp_buf) { if (hipMalloc((void**)&g_stamp_buf, kStampBlocks * 64) != hipSuccess) g_stamp_buf = nullptr; }
         if (g_stamp_buf && nblocks <= kStampBlocks) {
             (void)hipMemsetAsync(g_stamp_buf, 0, (size_t)kStampBlocks * 64, s);
@@ -1830,54 +2049,57 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
             st = g_stamp_buf;
         }
     }
-#define PF_GO(F, H, T, S, I) hipLaunchKernelGGL((k_levels<F, H, T, S, I>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
+#define PF_GO(F, H, T, S, I, P, W) hipLaunchKernelGGL((k_levels<F, H, T, S, I, P, W>), dim3(nblocks), dim3(T), 0, s, batch, w, src, st)
+    if (st) {                                          // stamped instantiations (tools/stamp_phases.py, tools/count_wins.py) of the product's forms, or of the deferred one
+        g_form_counts[6]++;
+        if (wplane) { if (lay.f32) PF_GO(true, 32, 512, true, 3, false, false); else PF_GO(false, 32, 512, true, 2, false, false); }
+        else        { if (lay.f32) PF_GO(true, 32, 512, true, 0, false, true);  else PF_GO(false, 32, 512, true, 2, false, true); }
+        return;
+    }
     // level 0 with LDS-staged source patches when the frame's map allows it (patch_plan)
-    if (batch.tab0_n) g_form_counts[7]++;
-    if (st) g_form_counts[6]++;
-    if (wa && !st && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
+    if (wa && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
         g_form_counts[2]++;
-        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
-        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        if (lay.f32) PF_GO(true, 32, 512, false, 2, true, false); else PF_GO(false, 32, 512, false, 2, true, false);
         return;
     }
-    // Default form of the pipelined launch: the radial weight computed in the kernel (radial_weight) -- two gathers per
-    // warped pixel instead of three.  Measured on MI355X (profiles/r03_ab.md): fp32 +1.8 %, int16 +-0 against the weight
-    // plane gather; PF_WEIGHT_PLANE=1 selects the gather (also what fused = 0/2/3 and the other block shapes use).
-    static const bool wplane = getenv("PF_WEIGHT_PLANE") != nullptr;
-    if (wa && !wplane && !st && BH == 28 && radial_weight_exact(*wa)) {
-        g_form_counts[5]++;
-        // PF_BLOCK28 (A/B): 64x28 blocks stage 35 rows = five whole passes of the 7 rows 512 threads warp at a time (a 64x32 block
-        // stages 39 rows in six passes: 42 row slots for 39 rows)
-        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
-        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 28, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
-        else         hipLaunchKernelGGL((k_levels<false, 28, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+    if (BH == 28) {                                   // PF_BLOCK28 (A/B): 64x28 blocks stage 35 rows = five whole passes of the 7 rows 512 threads warp at a time
+        if (wa) g_form_counts[5]++;
+        if (wplane) { if (lay.f32) PF_GO(true, 28, 512, false, 3, false, false); else PF_GO(false, 28, 512, false, 2, false, false); }
+        else        { if (lay.f32) PF_GO(true, 28, 512, false, 3, false, true);  else PF_GO(false, 28, 512, false, 2, false, true); }
         return;
     }
-    if (wa && !wplane && !st && BH == 32 && (ilp == 3 || ilp == 2) && radial_weight_exact(*wa)) {
-        g_form_counts[0]++;
-        w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
-        if (lay.f32) {
-            if (ilp == 3) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
-            else          hipLaunchKernelGGL((k_levels<true, 32, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+    if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)
+        if (wa) g_form_counts[4]++;
+        if (lay.f32) PF_GO(true, 64, 1024, false, 3, false, false); else PF_GO(false, 64, 1024, false, 2, false, false);
+        return;
+    }
+    if (ilp_env == 0 && !wplane && !lay.f32) {        // int16 with deferred finishes
+        if (wa) g_form_counts[0]++;
+        PF_GO(false, 32, 512, false, 0, false, true);
+        return;
+    }
+    if (ilp_env == 2 || ilp_env == 3) {               // the row loops of rounds 2-4
+        if (wa) g_form_counts[wplane ? 1 : 0]++;
+        if (wplane) {
+            if (lay.f32) { if (ilp_env == 3) PF_GO(true, 32, 512, false, 3, false, false); else PF_GO(true, 32, 512, false, 2, false, false); }
+            else         { if (ilp_env == 3) PF_GO(false, 32, 512, false, 3, false, false); else PF_GO(false, 32, 512, false, 2, false, false); }
         } else {
-            if (ilp == 3) hipLaunchKernelGGL((k_levels<false, 32, 512, false, 3, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
-            else          hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+            if (lay.f32) { if (ilp_env == 3) PF_GO(true, 32, 512, false, 3, false, true); else PF_GO(true, 32, 512, false, 2, false, true); }
+            else         { if (ilp_env == 3) PF_GO(false, 32, 512, false, 3, false, true); else PF_GO(false, 32, 512, false, 2, false, true); }
         }
         return;
     }
-    if (wa) g_form_counts[BH == 64 ? 4 : (BH == 28 ? 5 : 1)]++;
-    if (BH == 28) {
-        if (lay.f32) PF_GO(true, 28, 512, false, 3); else PF_GO(false, 28, 512, false, 2);
-    } else
-    if (BH == 64) {                                   // PF_BLOCK64 (A/B, see level_block_rows)
-        if (lay.f32) { if (ilp == 3) PF_GO(true, 64, 1024, false, 3); else PF_GO(true, 64, 1024, false, 2); }
-        else if (st) PF_GO(false, 64, 1024, true, 3); else if (ilp == 3) PF_GO(false, 64, 1024, false, 3); else PF_GO(false, 64, 1024, false, 2);
-    } else if (lay.f32) {
-        if (st) PF_GO(true, 32, 512, true, 3); else if (ilp == 3) PF_GO(true, 32, 512, false, 3); else PF_GO(true, 32, 512, false, 2);
-    } else {
-        if (st) PF_GO(false, 32, 512, true, 3); else if (ilp == 3) PF_GO(false, 32, 512, false, 3); else PF_GO(false, 32, 512, false, 2);
-    }
 #undef PF_GO
+#endif
+    // the product's forms: weight computed or gathered
+    if (wa) g_form_counts[wplane ? 1 : 0]++;
+    if (wplane) {
+        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 3, false, false>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, false, false>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+    } else {
+        if (lay.f32) hipLaunchKernelGGL((k_levels<true, 32, 512, false, 0, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+        else         hipLaunchKernelGGL((k_levels<false, 32, 512, false, 2, false, true>), dim3(nblocks), dim3(512), 0, s, batch, w, src, st);
+    }
 }
 
 // rows of a level-kernel block: 32 (512 threads, three workgroups per CU).  PF_BLOCK64=1 (A/B): 64 rows x 1024 threads, halo
@@ -1885,9 +2107,13 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
 // Measured on MI355X, cfg-A: int16 -23 %, fp32 -18 %
 int level_block_rows(bool f32)
 {
-    static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr;
     (void)f32;
+#if PF_EXPERIMENTS
+    static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr;
     return b64 ? 64 : (b28 ? 28 : 32);
+#else
+    return 32;
+#endif
 }
 
 // diagnostics (PF_STAMP=1): pixels seen / won by stage D per level since the last reset; out[2 * level] = seen, [2 * level + 1] = won

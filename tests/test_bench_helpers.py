@@ -56,3 +56,38 @@ def test_pmc_record_carries_its_build():
     r = bench.pmc_record("f32", "level0_fused")
     assert r is None or ({"traffic", "git_sha", "kernels_sha", "current"} <= set(r) and isinstance(r["current"], bool))
     assert len(bench.kernels_sha()) == 16
+
+
+def test_roofline_numerator_follows_the_canvas_share_that_ran():
+    """roofline.frac counts the bytes of what the launches' blocks processed (alg_bytes_run), not SURVEY 8d's bytes of every canvas tile
+    (VERDICT r04 item 1): with the frame read once (36 MB) and 377.8 MB of tile bytes, the numerator must scale with the run share."""
+    S, T = 36e6, 377.8e6
+    recs = []
+    for share in (1.0, 0.687, 0.5):
+        p = {"ms": 0.12009 * 5, "launches": 5, "alg_bytes": (S + T) * 5, "alg_bytes_run": (S + T * share) * 5}
+        recs.append(bench.roofline_record("level0_fused", p, "f32", 4, pmc_ok=False, window=bench.window_key(20, 5, 15)))
+    full, driver, half = recs
+    assert full["frac"] == full["frac_full_canvas"]
+    assert driver["frac_full_canvas"] == full["frac_full_canvas"]                # the old number does not move with the cull ...
+    assert abs(driver["frac"] - (S + T * 0.687) / (S + T) * full["frac"]) < 2e-4  # ... the new one does
+    assert abs(driver["frac"] - 0.3076) < 2e-3                                  # VERDICT r04's recomputation of the r04 driver window: 0.31
+    assert half["alg_bytes_run_per_launch"] == round(S + T * 0.5) and half["frac"] < driver["frac"] < full["frac"]
+    assert driver["window"] == "k20_w5_pre15" and driver["traffic"] is None and driver["frac_delivered"] is None
+
+
+def test_pmc_records_are_keyed_by_window(tmp_path, monkeypatch):
+    import json
+    d = tmp_path / "profiles"; d.mkdir()
+    (d / "pmc_traffic.json").write_text(json.dumps({
+        "_meta": {"git_sha": "x", "kernels_sha": "y"},
+        "f32": {"level0_fused": {"windows": {"k200_w20_pre0": {"traffic": 350, "valu_insts": 7, "launches": 200},
+                                             "k20_w5_pre15": {"traffic": 400, "launches": 20}}}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernels_sha", lambda: "y")
+    assert bench.pmc_record("f32", "level0_fused", "k20_w5_pre15")["traffic"] == 400
+    assert bench.pmc_record("f32", "level0_fused", "k200_w20_pre0")["current"] is True
+    assert bench.pmc_record("f32", "level0_fused", "k20_w5_pre15_nocull") is None      # no pass of its own: no number
+    p = {"ms": 0.1 * 20, "launches": 20, "alg_bytes": 4e8 * 20, "alg_bytes_run": 3e8 * 20}
+    r = bench.roofline_record("level0_fused", p, "f32", 4, True, "k20_w5_pre15")
+    assert r["traffic"] == 400 and r["frac_delivered"] is not None and r["pmc_build"]["launches_averaged"] == 20
+    assert bench.roofline_record("level0_fused", p, "f32", 4, True, "k20_w5_pre15_nocull")["traffic"] is None

@@ -8,6 +8,8 @@ tests in a child process (the switches are read once per process):
   PF_BLOCK28=1       64x28 blocks
   PF_CULL=0          every tile of every canvas rendered (no cull)
   PF_CULL_SUB=2      the cull per quadrant of a tile instead of per 64 x 64 cell
+Forms that were measured and not adopted live in the second build of the library (libpifusion_exp.so, -DPF_EXPERIMENTS=1), which the
+child processes load through PF_LIB; the product library carries the product instantiations only.
 Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:311-558 (renderFrame)."""
 import os
 import subprocess
@@ -21,6 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # which counter of pf_debug_form_counts must (or must not) move under a switch: the parity run alone would also pass on a silent
 # fall-back to the default form
+EXP_LIB = os.path.join(ROOT, "pi-slam-fusion_amd", "libpifusion_exp.so")
+NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28"}
 FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
         "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
         "PF_CULL=0": "culled == 0 and c[0] > 0", "PF_CULL_SUB=2": "culled > 0 and g.culled_cells() % 4 == 0 and c[0] > 0"}
@@ -48,6 +52,9 @@ assert %s, (c, culled)
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
+    if name in NEEDS_EXP:
+        assert os.path.exists(EXP_LIB), "build the experiments library first (__graft_entry__.build())"
+        env["PF_LIB"] = EXP_LIB
     # the requested form really runs (and gives the oracle's tiles) ...
     probe = PROBE % (ROOT, os.path.join(ROOT, "tests"), FORM[switch])
     r = subprocess.run([sys.executable, "-c", probe], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)

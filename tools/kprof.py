@@ -8,6 +8,7 @@ import bench
 ap = argparse.ArgumentParser(); ap.add_argument("--int16", action="store_true"); ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--fused", type=int, default=1); ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--mul", type=int, default=1, help="frame edge multiplier (2: 8000x6000 frames)")
+ap.add_argument("--no-events", action="store_true", help="no HIP events around the launches (under rocprofv3 --kernel-trace: the trace's own durations)")
 a = ap.parse_args()
 import torch
 pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")
@@ -18,7 +19,7 @@ assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
 fr = [torch.randint(0, 256, (cam[1], cam[0], 3), dtype=torch.uint8, device="cuda") for _ in range(4)]
 torch.cuda.synchronize()
 for k in range(20): m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k])
-m.sync(); m.profile_enable(1)
+m.sync(); m.profile_enable(0 if a.no_events else 1)
 import time
 t0 = time.perf_counter()
 for k in range(20, 20 + a.frames): m.feed_device(fr[k % 4].data_ptr(), cam[1], cam[0], poses[k])

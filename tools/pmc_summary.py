@@ -3,6 +3,8 @@
 
   kernel stats : tools/pmc_summary.py stats <dir with *_kernel_stats.csv> > profiles/<name>.md
   HBM traffic  : tools/pmc_summary.py traffic <fetch dir> <write dir> <dtype> [profiles/pmc_traffic.json] [<SQ_INSTS_VALU dir>]
+                 with PF_WINDOW="K W PRE [nocull]" in the environment: only the K TIMED launches of `bench.py --steps K --warmup W`
+                 (PRE keyframes flown before the warm-up) are averaged, and the record goes under windows[bench.window_key(...)]
   SQ counters  : tools/pmc_summary.py counters <pmc dir> ...
 
 The JSON records the build it was taken at (_meta.git_sha, _meta.kernels_sha = bench.kernels_sha()); bench.py
@@ -79,10 +81,31 @@ def full_launches(d):
           (len(dur), len(rows), sum(dur) / len(dur), min(dur), max(dur)))
 
 
+def window():
+    """PF_WINDOW="K W PRE [nocull]": (K, W, PRE, nocull) or None"""
+    w = os.environ.get("PF_WINDOW", "").split()
+    if len(w) < 3:
+        return None
+    return int(w[0]), int(w[1]), int(w[2]), len(w) > 3 and w[3] == "nocull"
+
+
 def counter_rows(d):
     """rows of a --pmc pass; the pipelined k_levels launches are kept only at full size (a keyframe's launch), not
-    the short flush launches before a sync that carry upper levels only -- the same launches bench.py times"""
+    the short flush launches before a sync that carry upper levels only -- the same launches bench.py times.
+    With PF_WINDOW: only the full-size launches PRE + W .. PRE + W + K - 1 of the process (bench.py --no-cpu feeds one map: PRE keyframes,
+    W warm-up keyframes, K timed ones, one full-size launch each)."""
     rows = [r for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))) if short(r["Kernel_Name"])]
+    win = window()
+    if win:
+        # by position: PRE keyframe launches (+ L-1 = 4 short flush launches at the sync behind them), W launches + 4, K launches + 4
+        K, W, PRE, _ = win
+        nf = int(os.environ.get("PF_FLUSH_LAUNCHES", "4"))
+        ids = sorted({int(r["Dispatch_Id"]) for r in rows if pipelined(r["Kernel_Name"])})
+        if len(ids) != PRE + W + K + nf * (2 + (PRE > 0)):
+            raise SystemExit("window %s: %d pipelined launches in the pass, %d expected" % (win, len(ids), PRE + W + K + nf * (2 + (PRE > 0))))
+        start = PRE + (nf if PRE else 0) + W + nf
+        keep = set(ids[start:start + K])
+        return [r for r in rows if not pipelined(r["Kernel_Name"]) or int(r["Dispatch_Id"]) in keep]
     full = max([int(r["Grid_Size"]) for r in rows if pipelined(r["Kernel_Name"])] or [0])
     return [r for r in rows if not pipelined(r["Kernel_Name"]) or int(r["Grid_Size"]) * 2 > full]
 
@@ -126,7 +149,15 @@ def traffic(fd, wd, dtype, out, vd=None):
         if cur.get("_meta", {}).get("kernels_sha") != meta["kernels_sha"]:
             cur = {}                                  # numbers of another build do not mix
         cur["_meta"] = meta
-        cur[dtype] = res
+        win = window()
+        if win:
+            import bench
+            key = bench.window_key(*win)
+            for k in res:
+                res[k]["launches"] = nf.get(k, 0)
+                cur.setdefault(dtype, {}).setdefault(k, {}).setdefault("windows", {})[key] = res[k]
+        else:
+            cur[dtype] = res
         json.dump(cur, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res))
 

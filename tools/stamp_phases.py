@@ -30,7 +30,7 @@ n = L.pf_debug_phase_stamps(None, 1 << 16)
 buf = np.zeros((n, 8), np.uint64)
 assert L.pf_debug_phase_stamps(buf.ctypes.data, n) == n
 buf = buf[buf[:, 0] > 0]
-names = ["A (stage + warp)", "wait at barrier 1", "B (pyrDown)", "wait at barrier 2", "D (Laplacian, select, stores drained)"]
+names = ["A (table entry, stage + warp)", "wait at barrier 1", "B (pyrDown)", "wait at barrier 2", "D (Laplacian, select, stores drained)"]
 # s_memtime counters of different XCDs do not share a base: spans are formed per XCD (stamp slot 7 = XCC id)
 spans = []
 for x in sorted(set(buf[:, 7].astype(int))):
@@ -38,8 +38,13 @@ for x in sorted(set(buf[:, 7].astype(int))):
     spans.append(int(bx[:, 5].max() - bx[:, 0].min()))
 print("%d stamped workgroups on %d XCDs; launch span per XCD: median %d ticks (min %d, max %d)" %
       (len(buf), len(spans), int(np.median(spans)), min(spans), max(spans)))
+entry = (buf[:, 6] >> np.uint64(4)).astype(np.int64)          # s_memtime at kernel entry (slot 6 = job | entry << 4)
+buf[:, 6] &= np.uint64(15)
 for job in sorted(set(buf[:, 6].astype(int))):
-    b = buf[buf[:, 6] == job].astype(np.int64)
+    sel = buf[:, 6] == job
+    b = buf[sel].astype(np.int64)
+    pro = b[:, 0] - entry[sel]
+    print("job %d: prologue (kernel entry -> block start: job pick, need test, scalar loads) mean %7.0f  median %7.0f  p90 %7.0f ticks" % (job, pro.mean(), np.median(pro), np.percentile(pro, 90)))
     d = np.diff(b[:, :6], axis=1)
     life = b[:, 5] - b[:, 0]
     print("job %d: %5d workgroups, lifetime mean %7.0f ticks (min %d, max %d)" % (job, len(b), life.mean(), life.min(), life.max()))
