@@ -289,6 +289,9 @@ void    pf_set_cull(pf_map* m, int on);
  * [1] block form gathering the weight plane, [2] LDS-staged source patch, [3] rolling strips, [4] 64x64 blocks, [5] 64x28 blocks,
  * [6] stamped instantiation, [7] launches whose tile table travelled in the kernel arguments.  Diagnostics (variant tests). */
 void    pf_debug_form_counts(long long out[8]);
+/* ... and how many of them ran their level-0 job on the compact grid (one workgroup per block inside the need rectangles of a shard / of
+ * the cull, instead of one per block of the canvas' bounding box) */
+long long pf_debug_compact_launches(void);
 /* frames rendered / rejected since creation */
 int     pf_stats(pf_map* m, long long* rendered, long long* rejected, long long* dropped);
 /* Allocator hint, no reference counterpart (MultiBandMap2DCPUEle's cv::Mat tiles, MultiBandMap2DCPU.h:32-51,

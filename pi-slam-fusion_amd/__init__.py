@@ -119,6 +119,8 @@ def lib():
     L.pf_dist_set_verify.argtypes = [vp, C.c_int]
     L.pf_dist_plan_blend.argtypes = [C.c_int, C.c_int, ip, ip, C.POINTER(C.c_longlong), C.c_int, C.POINTER(C.c_size_t), vp, C.c_int, ip,
                                      vp, C.c_int, ip, ip, C.c_int, ip]
+    if hasattr(L, "pf_debug_compact_launches") or not os.environ.get("PF_LIB"):
+        L.pf_debug_compact_launches.argtypes = []; L.pf_debug_compact_launches.restype = C.c_longlong
     L.pf_profile_enable.argtypes = [vp, C.c_int]
     L.pf_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), dp, C.POINTER(C.c_longlong), dp]
     # (PF_LIB may name an older build of the library for an A/B round, tools/ab.sh: it lacks this round's entry points)

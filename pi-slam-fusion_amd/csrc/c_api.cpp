@@ -60,6 +60,7 @@ int pf_feed(pf_map* m, const pf_image* img, const double pose[7]) { return m && 
 int pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]) { return m && m->impl.feed(img, pose, true); }
 int pf_debug_phase_stamps(unsigned long long* out, int cap_blocks) { return pf::read_phase_stamps(out, cap_blocks); }
 void pf_debug_form_counts(long long out[8]) { if (out) pf::read_form_counts(out); }
+long long pf_debug_compact_launches(void) { return pf::read_compact_launches(); }
 int pf_debug_render_log(pf_map* m, long long* out, int cap) { return m ? m->impl.render_log(out, cap) : 0; }
 void pf_set_cull(pf_map* m, int on) { if (m) m->impl.set_cull(on != 0); }
 long long pf_debug_culled_cells(pf_map* m) { return m ? m->impl.culled_cells() : 0; }

@@ -31,6 +31,16 @@ int tile_owner(int shard_count, int shard_block, int ix, int iy)
 {
     if (shard_count <= 1) return 0;
     const int b = shard_block > 0 ? shard_block : 8;
+    // PF_SHARD_OWNER=cyclic (evaluation only, tools/predict_scaling.py --owner cyclic; every rank must set it alike): SURVEY 8e's other
+    // candidate, a 2-D block-cyclic owner -- cells dealt over a px x py grid of ranks (px * py = shard_count, px the larger factor), so that
+    // neighbouring cells never share a rank and any px x py window of cells holds every rank once
+    static const bool cyclic = std::getenv("PF_SHARD_OWNER") && std::string(std::getenv("PF_SHARD_OWNER")) == "cyclic";
+    if (cyclic) {
+        int py = 1;
+        for (int d = 1; d * d <= shard_count; d++) if (shard_count % d == 0) py = d;
+        const int px = shard_count / py, cxs = floordiv(ix, b), cys = floordiv(iy, b);
+        return ((cxs % px) + px) % px + px * (((cys % py) + py) % py);
+    }
     const uint32_t cx = (uint32_t)floordiv(ix, b), cy = (uint32_t)floordiv(iy, b);
     const uint32_t h = (cx * 73856093u) ^ (cy * 19349663u);
     return (int)(h % (uint32_t)shard_count);

@@ -375,7 +375,8 @@ struct LevelArgs {
 };
 // by = b / nbx by one multiply: with inv = ceil(2^32 / nbx), floor(b * inv / 2^32) = floor(b / nbx) while b * (inv * nbx - 2^32) < 2^32, which
 // nblk * nbx < 2^32 guarantees (level_inv_nbx); inv_nbx == 0: the division itself
-__device__ __forceinline__ void block_xy(const LevelArgs& g, int b, int& bx, int& by)
+template <class GA>      // LevelArgs in registers / on the stack, or where it lies in the kernel arguments (address space 4)
+__device__ __forceinline__ void block_xy(const GA& g, int b, int& bx, int& by)
 {
     if (g.inv_nbx) by = (int)__umulhi((unsigned)b, g.inv_nbx); else by = b / g.nbx;
     bx = b - by * g.nbx;
@@ -977,8 +978,8 @@ __device__ unsigned long long g_select_seen[kMaxLevels], g_select_won[kMaxLevels
 // bytes of LDS a PATCH workgroup has behind A for the source patch (Bt lives there after stage A): two workgroups per CU
 constexpr int kPatchBytes = 81920 - 44928;
 
-template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
-__device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOffsets& lay, const LevelArgs& g, const FusedWarp& wa,
+template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false, class LO = LevelOffsets, class GA = LevelArgs>
+__device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay, const GA& g, const FusedWarp& wa,
                                              const uint8_t* __restrict__ src, const PxT<F32>* __restrict__ gw_in,
                                              PxT<F32>* __restrict__ gw_out, const uint64_t* __restrict__ table_generic, const int b,
                                              unsigned long long* stamps = nullptr, const uint64_t* tab0 = nullptr)
@@ -1044,6 +1045,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
     }
 
     // ---- A
+    // A/B (PF_ABLATE bits 1024 / 2048): static priority for the younger / the older half of the workgroup's waves during stage A (a SIMD serves
+    // the older of its two waves of a workgroup first, and wave 0 waits ~3000 cycles at the barrier behind stage A for the younger ones)
+    if (kExp && FROM_WARP && (g.ablate & 1024) && tid >= LNT / 2) __builtin_amdgcn_s_setprio(1);
+    if (kExp && FROM_WARP && (g.ablate & 2048) && tid < LNT / 2) __builtin_amdgcn_s_setprio(1);
     if (FROM_WARP) {
         // a thread keeps one column of A and walks down it LNT / LAW rows at a time: the column terms of the
         // coordinate are formed once
@@ -1286,9 +1291,15 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LevelOf
         stage_from_hbm<F32, LAH, LNT, true>(&A[0][0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
     }
     if (STAMP) phase_stamp(stamps, 1);
+    if (kExp && FROM_WARP && (g.ablate & (1024 | 2048))) __builtin_amdgcn_s_setprio(0);
     lds_barrier();
     if (STAMP) phase_stamp(stamps, 2);
     if (kExp && (g.ablate & 2)) return;
+    // A never-taken exit (levels are >= 0).  With an exit here the compiler keeps stages B / D's address arithmetic below the barrier; without
+    // one it hoists part of it above stage A, the fp32 kernel goes three VGPRs over its budget of 80, spills them to scratch, and the launch is
+    // 3.6 % slower (same box, interleaved: profiles/r05_ab.md, "product against experiments build").  The experiments build has such an exit
+    // anyway (PF_ABLATE, the line above), which is how the difference was found.
+    if (!kExp && g.level < 0) return;
     if (kExp && (g.ablate & 256)) __builtin_amdgcn_s_setprio(2);           // A/B: the short memory-bound stages ahead of other workgroups' warp
 
     // stored weights of the quad: in flight during stage B
@@ -1605,7 +1616,11 @@ __device__ __forceinline__ void load_words(const char PF_CONST* p, uint32_t (&w)
     for (; i + 4 <= N; i += 4) { const su4 v = *(const su4 PF_CONST*)(p + 4 * i); for (int k = 0; k < 4; k++) w[i + k] = v[k]; }
 }
 
-struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0; LevelJob job[kMaxLevels - 1]; BlockRect rect0[kMaxRects]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
+// compact0 (job 0 with need rectangles that cover well under its whole grid -- a shard's scattered hash cells above all): the launch carries
+// one workgroup per block INSIDE the rectangles instead of one per block of the grid; rect_first[k] = blocks of rectangles 0 .. k-1,
+// compact0 = their total, rect_inv[k] = ceil(2^32 / width of rectangle k) (0: width 1).  A block that lies in two rectangles runs in the first.
+struct LevelBatch { int njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0, compact0; LevelJob job[kMaxLevels - 1]; BlockRect rect0[kMaxRects];
+                    int rect_first[kMaxRects]; unsigned rect_inv[kMaxRects]; uint32_t need_bits[kNeedWords]; uint64_t tab0[kArgTable]; };
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 2 * sizeof(void*) <= 4096, "kernel arguments of k_levels: 4 KB");
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -1626,7 +1641,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     const LevelBatch PF_CONST& B = *(const LevelBatch PF_CONST*)ka;          // `batch` as it lies in the kernel-argument segment: every access a scalar load
     (void)batch;
     static_assert(offsetof(LevelBatch, job) == 32, "the header is one s_load_dwordx8");
-    const su8 hdr = *(const su8 PF_CONST*)ka;                                // njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0
+    const su8 hdr = *(const su8 PF_CONST*)ka;                                // njobs, upper_groups, total_groups, sequential, tab0_n, rect_runs, need_r0, compact0
     su16 ja = *(const su16 PF_CONST*)(ka + 32); su4 jb = *(const su4 PF_CONST*)(ka + 32 + 64);      // job 0: LevelArgs | first, from_warp, nrect, bits_off
     int first[kMaxLevels];
 #pragma unroll
@@ -1635,7 +1650,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     asm volatile("" :: "s"(hdr), "s"(ja), "s"(jb));
     asm volatile("" :: "s"(first[1]), "s"(first[2]), "s"(first[3]), "s"(first[4]), "s"(first[5]), "s"(first[6]), "s"(first[7]));
     static_assert(kMaxLevels == 9, "first[1..7]: a launch carries at most kMaxLevels - 1 level jobs");
-    const int njobs = (int)hdr[0], ug = (int)hdr[1], tg = (int)hdr[2], seq = (int)hdr[3], tab0_n = (int)hdr[4], rect_runs = (int)hdr[5], need_r0 = (int)hdr[6];
+    const int njobs = (int)hdr[0], ug = (int)hdr[1], tg = (int)hdr[2], seq = (int)hdr[3], tab0_n = (int)hdr[4], rect_runs = (int)hdr[5], need_r0 = (int)hdr[6], compact0 = (int)hdr[7];
     const int g = (int)blockIdx.x >> 3, lane8 = (int)blockIdx.x & 7;
     int u0, u1;
     if (!kExp || seq == 1) { u0 = g < tg - ug ? 0 : g - (tg - ug); u1 = g < tg - ug ? 0 : u0 + 1; }      // upper levels last (default; the product's only order)
@@ -1667,11 +1682,38 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     }
     const LevelJob PF_CONST& Jc = B.job[j];
     const int nblk = J.g.nbx * J.g.nby;
-    if (b >= nblk) return;                                     // padding up to the next multiple of 8
-    // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
-    // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
-    const int rr = kExp ? rect_runs : 0;                  // PF_RECT_ORDER (A/B): 1 XCD runs even with rectangles, 2 round robin always, >= 3 runs of 4 / 8 / 16 blocks
-    const int bb = rr >= 3 ? xcd_chunks(b, nblk, 1 << (rr - 1)) : ((J.nrect && !rr) || rr == 2) ? b : xcd_order(b, nblk);
+    int bb;
+    if (j == 0 && compact0) {
+        // one workgroup per block inside the need rectangles: b -> rectangle k -> (bx, by); everything in one round of loads
+        if (b >= compact0) return;                             // padding up to the next multiple of 8
+        static_assert(kMaxRects == 8 && sizeof(BlockRect) == 8, "rect0 is one s_load_dwordx16, rect_first / rect_inv one s_load_dwordx8 each");
+        const su16 rw = *(const su16 PF_CONST*)(ka + offsetof(LevelBatch, rect0));
+        const su8 rf = *(const su8 PF_CONST*)(ka + offsetof(LevelBatch, rect_first)), ri = *(const su8 PF_CONST*)(ka + offsetof(LevelBatch, rect_inv));
+        asm volatile("" :: "s"(rw), "s"(rf), "s"(ri));
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < kMaxRects; i++) if (i < J.nrect && b >= (int)rf[i]) k = i;
+        uint32_t lo = rw[0], hi = rw[1], fk = rf[0], ik = ri[0];
+#pragma unroll
+        for (int i = 1; i < kMaxRects; i++) if (k == i) { lo = rw[2 * i]; hi = rw[2 * i + 1]; fk = rf[i]; ik = ri[i]; }
+        const int rx0 = (short)(lo & 0xffff), ry0 = (short)(lo >> 16), rx1 = (short)(hi & 0xffff);
+        const unsigned local = (unsigned)b - fk, ly = ik ? __umulhi(local, ik) : local;
+        const int bx = rx0 + (int)(local - ly * (unsigned)(rx1 - rx0)), by = ry0 + (int)ly;
+        bool earlier = false;
+#pragma unroll
+        for (int i = 0; i < kMaxRects - 1; i++) {
+            const int ax0 = (short)(rw[2 * i] & 0xffff), ay0 = (short)(rw[2 * i] >> 16), ax1 = (short)(rw[2 * i + 1] & 0xffff), ay1 = (short)(rw[2 * i + 1] >> 16);
+            earlier = earlier || (i < k && bx >= ax0 && bx < ax1 && by >= ay0 && by < ay1);
+        }
+        if (earlier) return;                                   // this block runs in an earlier rectangle
+        bb = by * J.g.nbx + bx;
+    } else {
+        if (b >= nblk) return;                                 // padding up to the next multiple of 8
+        // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
+        // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
+        const int rr = kExp ? rect_runs : 0;                  // PF_RECT_ORDER (A/B): 1 XCD runs even with rectangles, 2 round robin always, >= 3 runs of 4 / 8 / 16 blocks
+        bb = rr >= 3 ? xcd_chunks(b, nblk, 1 << (rr - 1)) : ((J.nrect && !rr) || rr == 2) ? b : xcd_order(b, nblk);
+    }
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
     // (addressed through the kernel-argument segment pointer: taking the address of the by-value member costs registers)
@@ -1704,7 +1746,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     if (J.bits_off >= 0) {                                     // an upper-level job with its need bitmap in the kernel arguments
         if (!((B.need_bits[J.bits_off + (bb >> 5)] >> (bb & 31)) & 1u)) return;
     } else
-    if (J.nrect) {                                             // a shard: does any tile of this rank depend on the block?
+    if (J.nrect && !(j == 0 && compact0)) {                    // a shard: does any tile of this rank depend on the block?  (compact0: it does by construction)
         int bx, by; block_xy(J.g, bb, bx, by);
         bool hit = false;
         for (int k = 0; k < J.nrect; k++) {
@@ -1719,9 +1761,14 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     }
     unsigned long long* st = nullptr;
     if (STAMP) { st = stamps + (size_t)blockIdx.x * 8; if (threadIdx.x == 0) { st[6] = (unsigned long long)j | t_entry << 4; st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 20) /* HW_REG_XCC_ID */; } }
-    const LevelOffsets lay{ Jc.lay.lap_off, Jc.lay.w_off, Jc.lay.top_lap_off, Jc.lay.top_w_off };
-    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH, WA>(J.from_warp != 0, lay, J.g, wa, src, (const PxT<F32>*)Jc.gw_in, (PxT<F32>*)Jc.gw_out,
-                                                       Jc.table, bb, st, tab0);
+    // The block itself reads the job's fields where they lie in the kernel arguments, as it needs them (a scalar load behind other waves' work):
+    // kept in registers from the prologue on, the sixteen words of LevelArgs push the kernel over its SGPR budget and the spills cost VGPRs.  The
+    // laundered pointer keeps the compiler from forwarding the prologue's copies.
+    const char PF_CONST* kb = ka;
+    asm volatile("" : "+s"(kb));
+    const LevelJob PF_CONST& Jl = *(const LevelJob PF_CONST*)(kb + offsetof(LevelBatch, job) + j * sizeof(LevelJob));
+    level3_block<F32, LBH, LNT, STAMP, ILP, PATCH, WA>(J.from_warp != 0, Jl.lay, Jl.g, wa, src, (const PxT<F32>*)Jl.gw_in, (PxT<F32>*)Jl.gw_out,
+                                                       Jl.table, bb, st, tab0);
 }
 
 // radial_weight() forms dis = fma(dx, dx, dy * dy): one rounding, equal to the reference's RN(RN(dy^2) + RN(dx^2)) only while
@@ -1861,6 +1908,8 @@ static int g_stamp_blocks = 0;
 // 3 rolling strips; 4 64x64 blocks; 5 64x28 blocks; 6 stamped instantiation; 7 tile table in the kernel arguments
 static long long g_form_counts[8] = {};
 void read_form_counts(long long out[8]) { for (int i = 0; i < 8; i++) out[i] = g_form_counts[i]; }
+static long long g_compact_launches = 0;                          // pipelined launches whose level-0 job ran on the compact grid (LevelBatch::compact0)
+long long read_compact_launches() { return g_compact_launches; }
 
 #if PF_EXPERIMENTS
 // The wave-specialised rolling-strip form of the pipelined launch (strips.inc).  Returns false when this launch has to take
@@ -2002,6 +2051,27 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         if (batch.njobs == 0) { J.first = 0; first_blocks = padded; }
         else { J.first = upper_blocks; upper_blocks += padded; }
         batch.njobs++;
+    }
+    // job 0 with rectangles that cover at most three quarters of its grid: one workgroup per block inside them (LevelBatch::compact0).  A rank
+    // of 8 launched the whole canvas' 7072 level-0 blocks to run ~900 of them, and an empty workgroup still holds a slot for its ~2000-cycle prologue.
+    static const bool no_compact = kExp && getenv("PF_NO_COMPACT") != nullptr;      // A/B
+    if (!no_compact && batch.njobs && batch.job[0].from_warp && batch.job[0].nrect > 0 && BH == 32) {
+        const LevelJob& J0 = batch.job[0];
+        long total = 0; bool ok = true;
+        for (int r = 0; r < J0.nrect; r++) {
+            const BlockRect& q = batch.rect0[r];
+            const int w = q.x1 - q.x0, h = q.y1 - q.y0;
+            if (w < 0 || h < 0 || q.x0 < 0 || q.y0 < 0 || q.x1 > J0.g.nbx || q.y1 > J0.g.nby) { ok = false; break; }
+            batch.rect_first[r] = (int)total;
+            batch.rect_inv[r] = w > 1 ? (unsigned)((0x100000000ull + (unsigned)w - 1) / (unsigned)w) : 0u;
+            total += (long)w * h;
+        }
+        // (total > 0: workgroup 0 of job 0 also stores the frame's tile table for the later launches)
+        if (ok && total > 0 && total * 4 <= (long)J0.g.nbx * J0.g.nby * 3 && total < (1l << 24)) {
+            batch.compact0 = (int)total;
+            first_blocks = (int)((total + 7) & ~7l);
+            g_compact_launches++;
+        }
     }
     const int nblocks = first_blocks + upper_blocks;
     batch.upper_groups = upper_blocks / 8; batch.total_groups = nblocks / 8;

@@ -101,7 +101,8 @@ struct LevelLaunch {
 };
 void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs, int njobs, const WarpArgs* wa, const uint8_t* src);
 int  read_phase_stamps(unsigned long long* out, int cap_blocks);
-void read_form_counts(long long out[8]);                          // launches of the pipelined kernel by form (kernels.hip, g_form_counts)
+void read_form_counts(long long out[8]);
+long long read_compact_launches();                                // ... whose level-0 job ran one workgroup per block inside its need rectangles                          // launches of the pipelined kernel by form (kernels.hip, g_form_counts)
 int  read_select_counts(unsigned long long* out, int reset);       // diagnostics (PF_STAMP=1): [2*level] pixels stage D saw, [2*level+1] pixels that won
 // Reach (level-0 pixels) of the test by which the level-0 blocks of a pipelined launch decide for themselves whether they run (k_levels,
 // LevelBatch::need_r0): 0 when the launch takes the need rectangles instead.  table_n: entries of the frame's tile table if it travels in

@@ -134,6 +134,7 @@ def test_need_masks_over_ranks_cells_and_bands(pf, n, block, bands, force_float)
     poses = jitter_poses(5, seed=53 + n, step=(45.0, 28.0), yaw_deg=20, height=120.0)
     frames = [wl.noise_frame(1200, 1600, 900 + k) for k in range(len(poses))]
     (ref,) = build(pf, cam, poses, frames, 1, 1, force_float, band_number=bands, scale=1.5)
+    compact_before = pf.lib().pf_debug_compact_launches()
     shards = build(pf, cam, poses, frames, n, block, force_float, band_number=bands, scale=1.5)
     got = {}
     for m in shards:
@@ -144,3 +145,6 @@ def test_need_masks_over_ranks_cells_and_bands(pf, n, block, bands, force_float)
     if bands >= 3 and block >= 2 and n >= 3:
         rs = [m.render_stats() for m in shards if m.tiles()]
         assert min(r["level0_px"] / r["owned_px"] for r in rs) < 0.9 * n      # masks at work: less than the whole canvas each
+        # ... and the level-0 jobs of shards whose rectangles cover under three quarters of the canvas ran on the compact grid
+        # (one workgroup per block inside the rectangles: k_levels, LevelBatch::compact0)
+        assert pf.lib().pf_debug_compact_launches() > compact_before

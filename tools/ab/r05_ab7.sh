@@ -1,0 +1,7 @@
+O=gpurun_out/r05; mkdir -p $O
+E=$PWD/pi-slam-fusion_amd/libpifusion_exp.so; R=$PWD/tools/ab/lib_r04.so
+(time timeout -k 10 900 python -m pytest tests -m gpu -x -q) > $O/t7.log 2>&1; grep -E "passed|failed" $O/t7.log
+tools/abn.sh 3 "" "PF_LIB=$R" "PF_X=1" "PF_LIB=$E" "PF_LIB=$E PF_ABLATE=1024" "PF_LIB=$E PF_ABLATE=2048" > $O/ab7_f32.txt 2>&1
+tools/abn.sh 3 "--int16" "PF_LIB=$R" "PF_X=1" "PF_LIB=$E PF_ABLATE=1024" > $O/ab7_i16.txt 2>&1
+tools/abn.sh 3 "--steps 20 --warmup 5" "PF_LIB=$R" "PF_X=1" > $O/ab7_driver.txt 2>&1
+cat $O/ab7_f32.txt $O/ab7_i16.txt $O/ab7_driver.txt
