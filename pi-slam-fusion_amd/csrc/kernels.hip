@@ -356,6 +356,8 @@ struct FusedWarp {
     // formula (MultiBandMap2DCPU.cpp:403-417) with a correctly rounded square root and quotient, see radial_weight()
     float  wxc, wyc, wdmax, wrcp;   // x_center, y_center, dis_max, RN(1 / dis_max)
     int    wtype;                   // Map2D.WeightType
+    int    seed_ok;                 // host-checked (seed_plan): W changes by at most 2^-15 of itself from one canvas row to the next, anywhere on the
+                                    // canvas -- the reciprocal of a pixel's W may then start from the reciprocal of the pixel above it (rcp_seeded)
     float  Mf[9];           // M in fp32: only places the patch (a pixel outside it takes the global-memory path)
     int    phx, phy;        // half extents of the patch, source pixels
     int    pitch_i, pitch_w;// LDS row pitches of the frame patch and of the weight patch, bytes (multiples of 16)
@@ -388,6 +390,18 @@ __device__ __forceinline__ void block_xy(const GA& g, int b, int& bx, int& by)
 __device__ __forceinline__ double rcp_mid_range(double d)
 {
     double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
+    const double rem = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(rem, r, r);
+}
+
+// The same reciprocal from a SEED instead of v_rcp_f64 (16 issue cycles): r0 = RN(1 / d0) for a d0 within 2^-15 of d (relative).  Two Newton steps
+// take the seed's error 2^-15 to 2^-60, i.e. to the fma roundings' own 2^-53 -- exactly where v_rcp_f64 and two steps leave rcp_mid_range -- and
+// the same remainder correction rounds it; whatever makes that sequence the correctly rounded reciprocal makes this one so (checked against exact
+// rational arithmetic for seeds up to 2^-11 away: tests/test_oracle_ops.py::test_seeded_reciprocal_is_correctly_rounded).
+__device__ __forceinline__ double rcp_seeded(double d, double r)
+{
     double e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0); r = __builtin_fma(r, e, r);
     const double rem = __builtin_fma(-d, r, 1.0);
@@ -1209,18 +1223,22 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 const WarpCol col = warp_col(wa, ax0 + c);
                 const int cn = wa.cn, sstep = wa.sstep;
                 u2 b0[NR], b1[NR];
-                // the last pass holds rows for the first LAH - (NR - 1) * RS threads-rows only: a wave none of whose lanes has one skips it
-                const bool last = r0 + (NR - 1) * RS < LAH;
-                const bool any_last = __builtin_amdgcn_ballot_w64(last) != 0;
+                // A thread's rows are CONSECUTIVE (r0 * NR + k).  (Experiments build, PF_SEED=1: the reciprocal of row k + 1 starts from that of
+                // row k when the host found W to change slowly enough -- bit-exact, and no faster than one v_rcp_f64 per pixel: the row-to-row
+                // dependency costs what the instruction saves.)  The last thread rows run past the tile: a wave none of whose lanes has row k skips it.
+                const int rbase = r0 * NR;
+                const bool seed = kExp && wa.seed_ok != 0;          // experiments build only (PF_SEED=1): measured, no gain (profiles/r05_ab.md section 4)
+                double Wn = 0.0;
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
-                    if (k == NR - 1 && !any_last) break;
-                    const bool has = k < NR - 1 || last;
-                    const int r = has ? r0 + k * RS : r0;
+                    const bool has = rbase + k < LAH;
+                    if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) break;
+                    const int r = has ? rbase + k : rbase;
                     const int y = ay0 + r;
                     const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
                     const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
-                    const double Wn = rcp_mid_range(W);
+                    // (a lane past the tile re-does its first row: its seed is then five rows off, and its result is not stored)
+                    Wn = (k > 0 && seed) ? rcp_seeded(W, Wn) : rcp_mid_range(W);
                     const double pxn = xn * Wn, pyn = yn * Wn;
                     constexpr double kMagic = 6755399441055744.0;
                     const int Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
@@ -1235,10 +1253,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 }
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
-                    if (k == NR - 1 && !any_last) break;
-                    const bool has = k < NR - 1 || last;
+                    const bool has = rbase + k < LAH;
+                    if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) break;
                     if (!has) continue;
-                    const int r = r0 + k * RS;
+                    const int r = rbase + k;
                     const p2 pk = *reinterpret_cast<const p2*>(&Aat(r, c));
                     Aat(r, c) = warp_finish_fast<F32>(b0[k].x, b0[k].y, b1[k].x, b1[k].y, (int)(pk.x & 31u), (int)(pk.x >> 5), __uint_as_float(pk.y), cn);
                 }
@@ -1856,6 +1874,26 @@ static unsigned level_inv_nbx(int nbx, int nby)          // LevelArgs::inv_nbx, 
     return (unsigned)((0x100000000ull + (unsigned)nbx - 1) / (unsigned)nbx);
 }
 
+// FusedWarp::seed_ok: over the canvas and the blocks' 4-pixel halo W = M6 x + M7 y + M8 keeps one sign (affine: its extremes are at the corners)
+// and one canvas row changes it by at most 2^-16 of its smallest magnitude -- half the 2^-15 rcp_seeded is argued for, which itself sits
+// 2^3.5 inside the seed error at which its two Newton steps stop reaching the fma roundings' level.
+static int seed_plan(const double* M, int rows, int cols)
+{
+    static const bool on = kExp && getenv("PF_SEED") != nullptr;  // experiments build, on request: bit-exact and no faster than v_rcp_f64 per pixel
+    if (!on) return 0;
+    const double xs[2] = { -4.0, cols + 3.0 }, ys[2] = { -4.0, rows + 3.0 };
+    double wmin = 0; int sign = 0;
+    for (int i = 0; i < 4; i++) {
+        const double W = M[6] * xs[i & 1] + M[7] * ys[i >> 1] + M[8];
+        if (!(std::fabs(W) > 0x1p-400) || !std::isfinite(W)) return 0;
+        const int sg = W > 0 ? 1 : -1;
+        if (sign && sg != sign) return 0;
+        sign = sg;
+        wmin = i ? std::min(wmin, std::fabs(W)) : std::fabs(W);
+    }
+    return std::fabs(M[7]) <= 0x1p-16 * wmin;
+}
+
 size_t level_px_bytes(bool f32) { return f32 ? sizeof(PxT<true>) : sizeof(PxT<false>); }
 
 void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int cols, int cx0, int cy0, int cx1, int cy1,
@@ -2094,6 +2132,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         w.srows = wa->srows; w.scols = wa->scols; w.sstep = (int)wa->sstep; w.cn = wa->src_cn;
         w.plain = plain_homography(*wa);
         w.wxc = wa->xc; w.wyc = wa->yc; w.wdmax = wa->dis_max; w.wrcp = (float)(1.0L / (long double)wa->dis_max); w.wtype = wa->weight_type;
+        w.seed_ok = (w.plain && batch.job[0].from_warp) ? seed_plan(wa->M, batch.job[0].g.rows, batch.job[0].g.cols) : 0;
     }
     if (batch.tab0_n) g_form_counts[7]++;
     // The radial weight is computed in the kernel (radial_weight; two gathers per warped pixel instead of three: fp32 +1.8 %, int16 +-0

@@ -251,3 +251,28 @@ def test_weight_image_formula(orc):
     assert np.array_equal(w, e)
     assert w[0, 0] == np.float32(1e-5) and w[240, 320] == 1.0
     assert np.array_equal(orc.weight_image(9, 7, 1), np.maximum(orc.weight_image(9, 7, 0) ** 2, np.float32(1e-5)))
+
+
+def test_seeded_reciprocal_is_correctly_rounded():
+    """kernels.hip rcp_seeded (round 5): the fp64 reciprocal of W from the correctly rounded reciprocal of a NEIGHBOURING row's W -- two
+    Newton steps and the remainder correction, every step one fma -- must be the correctly rounded 1 / W, which is what the reference's
+    `32. / W` / `1. / W` divisions give (warpPerspective).  Exact rational arithmetic stands in for the fma unit.  The host
+    admits seeds at most 2^-16 away (seed_plan); the sequence is checked here up to 2^-12."""
+    import random
+    from fractions import Fraction as F
+
+    def fma(a, b, c):
+        return float(F(a) * F(b) + F(c))          # float(Fraction) rounds to nearest, ties to even
+
+    def seeded(W, r):
+        e = fma(-W, r, 1.0); r = fma(r, e, r)
+        e = fma(-W, r, 1.0); r = fma(r, e, r)
+        rem = fma(-W, r, 1.0)
+        return fma(rem, r, r)
+
+    rnd = random.Random(20260504)
+    for dexp in (12.0, 14.0, 16.0, 20.0):
+        for _ in range(1500):
+            W = rnd.uniform(0.5, 2.0) * rnd.choice([1.0, 3.7e-3, 911.0, -1.0, 2.0 ** -40])
+            W0 = W * (1.0 + rnd.uniform(-1.0, 1.0) * 2.0 ** -dexp)
+            assert seeded(W, float(F(1) / F(W0))) == float(F(1) / F(W)), (W, W0)

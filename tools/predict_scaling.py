@@ -92,11 +92,12 @@ for n in [int(v) for v in a.ranks.split(",")]:
         print(json.dumps(rec), flush=True)
 if a.md:
     with open(a.md, "w") as f:
-        f.write("| ranks | cell (tiles) | predicted kf/s | speed-up | efficiency | slowest / fastest rank (ms per 200 kf) | halo factor (max) | ranks with pixels per kf | "
-                "seam bytes, full redraw (max rank) | seam time over xGMI | feed P2P per kf |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
-        f.write("| 1 | -- | %.0f | 1.00 | 1.000 | %.1f | 1.0 | 1 | -- | -- | -- |\n" % (base_kfs, base["s"] * 1e3))
+        f.write("owner function: %s\n\n" % a.owner)
+        f.write("| ranks | cell (tiles) | predicted kf/s | speed-up | efficiency | slowest / fastest rank (ms per 200 kf) | us per keyframe, slowest rank | halo factor (max) | ranks with pixels per kf | "
+                "seam bytes, full redraw (max rank) | seam time over xGMI | feed P2P per kf |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("| 1 | -- | %.0f | 1.00 | 1.000 | %.1f | %.1f | 1.0 | 1 | -- | -- | -- |\n" % (base_kfs, base["s"] * 1e3, base["s"] / K * 1e6))
         for r in rows:
-            f.write("| %d | %d | %.0f | %.2f | %.3f | %.1f / %.1f | %.2f | %.2f | %.1f MB (%.1f MB) | %.2f ms | %.1f MB, %.0f us |\n" % (
+            f.write("| %d | %d | %.0f | %.2f | %.3f | %.1f / %.1f | %.1f | %.2f | %.2f | %.1f MB (%.1f MB) | %.2f ms | %.1f MB, %.0f us |\n" % (
                 r["ranks"], r["cell"], r["predicted_kfs"], r["speedup"], r["efficiency"], max(r["rank_seconds"]) * 1e3, min(r["rank_seconds"]) * 1e3,
-                max(r["halo_factor"]), r["ranks_with_pixels_per_keyframe"], r["seam_bytes_total"] / 1e6, r["seam_bytes_max_rank"] / 1e6, r["seam_ms_xgmi"],
+                max(r["rank_seconds"]) / K * 1e6, max(r["halo_factor"]), r["ranks_with_pixels_per_keyframe"], r["seam_bytes_total"] / 1e6, r["seam_bytes_max_rank"] / 1e6, r["seam_ms_xgmi"],
                 r["feed_p2p_bytes_per_keyframe"] / 1e6, r["feed_p2p_us_per_keyframe"]))
