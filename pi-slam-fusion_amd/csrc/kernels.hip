@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     const LevelJob PF_CONST& Jc = B.job[j];
     const int nblk = J.g.nbx * J.g.nby;
     int bb;
-    if (j == 0 && compact0) {
+    if (kExp && j == 0 && compact0) {          // experiments build, PF_COMPACT=1: measured, no change for a shard of 8 (profiles/r05_predicted_scaling.md)
         // one workgroup per block inside the need rectangles: b -> rectangle k -> (bx, by); everything in one round of loads
         if (b >= compact0) return;                             // padding up to the next multiple of 8
         static_assert(kMaxRects == 8 && sizeof(BlockRect) == 8, "rect0 is one s_load_dwordx16, rect_first / rect_inv one s_load_dwordx8 each");
@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
     if (J.bits_off >= 0) {                                     // an upper-level job with its need bitmap in the kernel arguments
         if (!((B.need_bits[J.bits_off + (bb >> 5)] >> (bb & 31)) & 1u)) return;
     } else
-    if (J.nrect && !(j == 0 && compact0)) {                    // a shard: does any tile of this rank depend on the block?  (compact0: it does by construction)
+    if (J.nrect && !(kExp && j == 0 && compact0)) {                    // a shard: does any tile of this rank depend on the block?  (compact0: it does by construction)
         int bx, by; block_xy(J.g, bb, bx, by);
         bool hit = false;
         for (int k = 0; k < J.nrect; k++) {
@@ -2091,9 +2091,10 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         batch.njobs++;
     }
     // job 0 with rectangles that cover at most three quarters of its grid: one workgroup per block inside them (LevelBatch::compact0).  A rank
-    // of 8 launched the whole canvas' 7072 level-0 blocks to run ~900 of them, and an empty workgroup still holds a slot for its ~2000-cycle prologue.
-    static const bool no_compact = kExp && getenv("PF_NO_COMPACT") != nullptr;      // A/B
-    if (!no_compact && batch.njobs && batch.job[0].from_warp && batch.job[0].nrect > 0 && BH == 32) {
+    // of 8 launches the whole canvas' 7072 level-0 blocks to run ~900 of them -- and yet the compact grid does not shorten its launches (49.3 k
+    // against 50.7 k predicted keyframes/s at 8 ranks, same box: the empty workgroups were not what a shard waits for).  Measured, not adopted.
+    static const bool compact = kExp && getenv("PF_COMPACT") != nullptr;            // experiments build, on request
+    if (compact && batch.njobs && batch.job[0].from_warp && batch.job[0].nrect > 0 && BH == 32) {
         const LevelJob& J0 = batch.job[0];
         long total = 0; bool ok = true;
         for (int r = 0; r < J0.nrect; r++) {

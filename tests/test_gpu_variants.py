@@ -6,6 +6,9 @@ tests in a child process (the switches are read once per process):
   PF_A_ILP=2 / 3     two / three warp rows per step for both pyramid types (defaults: fp32 3, int16 2)
   PF_STRIPS=1        the wave-specialised rolling-strip form (profiles/r04_strips.md)
   PF_BLOCK28=1       64x28 blocks
+  PF_A_ILP=0         int16: stage A with deferred finishes (fp32's product form)
+  PF_SEED=1          fp32: the reciprocal of a pixel's W seeded from the row above (kernels.hip rcp_seeded)
+  PF_COMPACT=1       a shard's level-0 job on the compact grid (one workgroup per block inside its need rectangles)
   PF_CULL=0          every tile of every canvas rendered (no cull)
   PF_CULL_SUB=2      the cull per quadrant of a tile instead of per 64 x 64 cell
 Forms that were measured and not adopted live in the second build of the library (libpifusion_exp.so, -DPF_EXPERIMENTS=1), which the
@@ -24,9 +27,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # which counter of pf_debug_form_counts must (or must not) move under a switch: the parity run alone would also pass on a silent
 # fall-back to the default form
 EXP_LIB = os.path.join(ROOT, "pi-slam-fusion_amd", "libpifusion_exp.so")
-NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28"}
+NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28", "PF_SEED", "PF_COMPACT"}
 FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
-        "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
+        "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_A_ILP=0": "c[0] > 0", "PF_SEED": "c[0] > 0", "PF_COMPACT": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
         "PF_CULL=0": "culled == 0 and c[0] > 0", "PF_CULL_SUB=2": "culled > 0 and g.culled_cells() % 4 == 0 and c[0] > 0"}
 PROBE = """
 import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -48,7 +51,8 @@ assert %s, (c, culled)
 """
 
 
-@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_STRIPS", "PF_BLOCK28", "PF_CULL=0", "PF_CULL_SUB=2"])
+@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_A_ILP=0", "PF_SEED", "PF_COMPACT", "PF_STRIPS", "PF_BLOCK28",
+                                    "PF_CULL=0", "PF_CULL_SUB=2"])
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
     env = dict(os.environ, **{name: val or "1"})
@@ -63,6 +67,8 @@ def test_variant_equals_oracle(switch):
     # fused=1 cases of the plumbing and perspective tests: both pyramid types, noise and smooth frames, 0..8 bands, spreadMap
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
            "-k", "(cfg1_plumbing or perspective_and_spread) and -1]"]
+    if name == "PF_COMPACT":        # the compact grid serves shards: the sharding tests, which assert that it ran
+        cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_sharding.py"), "-x", "-q", "-m", "gpu"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
     out = r.stdout.decode()
     assert r.returncode == 0 and " passed" in out, out[-3000:]
