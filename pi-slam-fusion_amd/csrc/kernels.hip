@@ -1222,7 +1222,10 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 using p2 = typename std::conditional<F32, park8, park4>::type;       // an int16 slot is 12 bytes
                 const WarpCol col = warp_col(wa, ax0 + c);
                 const int cn = wa.cn, sstep = wa.sstep;
-                u2 b0[NR], b1[NR];
+                // All NR rows of a thread at once (fp32), or in two halves (int16: twelve dwords of row data instead of twenty-four keep the kernel
+                // inside the 64 VGPRs of four workgroups per CU)
+                constexpr int CH = F32 ? NR : (NR + 1) / 2;
+                u2 b0[CH], b1[CH];
                 // A thread's rows are CONSECUTIVE (r0 * NR + k).  (Experiments build, PF_SEED=1: the reciprocal of row k + 1 starts from that of
                 // row k when the host found W to change slowly enough -- bit-exact, and no faster than one v_rcp_f64 per pixel: the row-to-row
                 // dependency costs what the instruction saves.)  The last thread rows run past the tile: a wave none of whose lanes has row k skips it.
@@ -1230,35 +1233,38 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 const bool seed = kExp && wa.seed_ok != 0;          // experiments build only (PF_SEED=1): measured, no gain (profiles/r05_ab.md section 4)
                 double Wn = 0.0;
 #pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    const bool has = rbase + k < LAH;
-                    if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) break;
-                    const int r = has ? rbase + k : rbase;
-                    const int y = ay0 + r;
-                    const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
-                    const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
-                    // (a lane past the tile re-does its first row: its seed is then five rows off, and its result is not stored)
-                    Wn = (k > 0 && seed) ? rcp_seeded(W, Wn) : rcp_mid_range(W);
-                    const double pxn = xn * Wn, pyn = yn * Wn;
-                    constexpr double kMagic = 6755399441055744.0;
-                    const int Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
-                    const int Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
-                    // 32 * p is exact, so the fused form rounds once, exactly as p * 32 + magic does
-                    const int X = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pxn, 32., kMagic));
-                    const int Y = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pyn, 32., kMagic));
-                    const float wgt = radial_weight(wa, Xn, Yn);
-                    const uint32_t off0 = (uint32_t)(__mul24(Y >> 5, sstep) + __mul24(cn, X >> 5));
-                    if (has) *reinterpret_cast<p2*>(&Aat(r, c)) = p2{ (uint32_t)((X & 31) | (Y & 31) << 5), __float_as_uint(wgt) };
-                    b0[k] = PF_LOAD_SRC((const u2*)(src + off0)); b1[k] = PF_LOAD_SRC((const u2*)(src + off0 + (uint32_t)sstep));
-                }
+                for (int h = 0; h < NR; h += CH) {
 #pragma unroll
-                for (int k = 0; k < NR; k++) {
-                    const bool has = rbase + k < LAH;
-                    if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) break;
-                    if (!has) continue;
-                    const int r = rbase + k;
-                    const p2 pk = *reinterpret_cast<const p2*>(&Aat(r, c));
-                    Aat(r, c) = warp_finish_fast<F32>(b0[k].x, b0[k].y, b1[k].x, b1[k].y, (int)(pk.x & 31u), (int)(pk.x >> 5), __uint_as_float(pk.y), cn);
+                    for (int k = h; k < h + CH && k < NR; k++) {
+                        const bool has = rbase + k < LAH;
+                        if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) continue;
+                        const int r = has ? rbase + k : rbase;
+                        const int y = ay0 + r;
+                        const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
+                        const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
+                        // (a lane past the tile re-does its first row: its seed is then five rows off, and its result is not stored)
+                        Wn = (k > 0 && seed) ? rcp_seeded(W, Wn) : rcp_mid_range(W);
+                        const double pxn = xn * Wn, pyn = yn * Wn;
+                        constexpr double kMagic = 6755399441055744.0;
+                        const int Xn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pxn + kMagic);
+                        const int Yn = (int)(uint32_t)(unsigned long long)__double_as_longlong(pyn + kMagic);
+                        // 32 * p is exact, so the fused form rounds once, exactly as p * 32 + magic does
+                        const int X = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pxn, 32., kMagic));
+                        const int Y = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pyn, 32., kMagic));
+                        const float wgt = radial_weight(wa, Xn, Yn);
+                        const uint32_t off0 = (uint32_t)(__mul24(Y >> 5, sstep) + __mul24(cn, X >> 5));
+                        if (has) *reinterpret_cast<p2*>(&Aat(r, c)) = p2{ (uint32_t)((X & 31) | (Y & 31) << 5), __float_as_uint(wgt) };
+                        b0[k - h] = PF_LOAD_SRC((const u2*)(src + off0)); b1[k - h] = PF_LOAD_SRC((const u2*)(src + off0 + (uint32_t)sstep));
+                    }
+#pragma unroll
+                    for (int k = h; k < h + CH && k < NR; k++) {
+                        const bool has = rbase + k < LAH;
+                        if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) continue;
+                        if (!has) continue;
+                        const int r = rbase + k;
+                        const p2 pk = *reinterpret_cast<const p2*>(&Aat(r, c));
+                        Aat(r, c) = warp_finish_fast<F32>(b0[k - h].x, b0[k - h].y, b1[k - h].x, b1[k - h].y, (int)(pk.x & 31u), (int)(pk.x >> 5), __uint_as_float(pk.y), cn);
+                    }
                 }
             }
         } else
