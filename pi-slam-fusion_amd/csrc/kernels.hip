@@ -26,6 +26,9 @@
 #ifndef PF_EXPERIMENTS
 #define PF_EXPERIMENTS 0
 #endif
+#ifndef PF_HYBRID_W          // A/B build switch: see level3_block, deferred stage A
+#define PF_HYBRID_W 0
+#endif
 
 namespace pf {
 
@@ -1226,6 +1229,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 // inside the 64 VGPRs of four workgroups per CU)
                 constexpr int CH = F32 ? NR : (NR + 1) / 2;
                 u2 b0[CH], b1[CH];
+                float wq[(CH + 1) / 2] = {};                       // gathered weights (A/B, see below): kept in registers until the finish
                 // A thread's rows are CONSECUTIVE (r0 * NR + k).  (Experiments build, PF_SEED=1: the reciprocal of row k + 1 starts from that of
                 // row k when the host found W to change slowly enough -- bit-exact, and no faster than one v_rcp_f64 per pixel: the row-to-row
                 // dependency costs what the instruction saves.)  The last thread rows run past the tile: a wave none of whose lanes has row k skips it.
@@ -1251,9 +1255,15 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                         // 32 * p is exact, so the fused form rounds once, exactly as p * 32 + magic does
                         const int X = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pxn, 32., kMagic));
                         const int Y = (int)(uint32_t)(unsigned long long)__double_as_longlong(__builtin_fma(pyn, 32., kMagic));
-                        const float wgt = radial_weight(wa, Xn, Yn);
+                        // A/B (build switch -DPF_HYBRID_W=1, tools/build_variant.sh): every other row GATHERS its weight from the plane instead of computing it -- the
+                        // vector pipes (radial_weight: ~22 instructions) and the address unit (one more load) share the weights between them
+                        constexpr bool kHyb = PF_HYBRID_W != 0; const bool gw_row = kHyb && (k & 1);
+                        float wgt;
+                        if (gw_row) wgt = *(const float*)((const char*)wa.wmap + ((uint32_t)(__mul24(Yn, wa.scols) + Xn) << 2));
+                        else wgt = radial_weight(wa, Xn, Yn);
                         const uint32_t off0 = (uint32_t)(__mul24(Y >> 5, sstep) + __mul24(cn, X >> 5));
-                        if (has) *reinterpret_cast<p2*>(&Aat(r, c)) = p2{ (uint32_t)((X & 31) | (Y & 31) << 5), __float_as_uint(wgt) };
+                        if (gw_row) wq[(k - h) >> 1] = wgt;
+                        if (has) *reinterpret_cast<p2*>(&Aat(r, c)) = p2{ (uint32_t)((X & 31) | (Y & 31) << 5), __float_as_uint(gw_row ? 0.f : wgt) };
                         b0[k - h] = PF_LOAD_SRC((const u2*)(src + off0)); b1[k - h] = PF_LOAD_SRC((const u2*)(src + off0 + (uint32_t)sstep));
                     }
 #pragma unroll
@@ -1263,7 +1273,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                         if (!has) continue;
                         const int r = rbase + k;
                         const p2 pk = *reinterpret_cast<const p2*>(&Aat(r, c));
-                        Aat(r, c) = warp_finish_fast<F32>(b0[k - h].x, b0[k - h].y, b1[k - h].x, b1[k - h].y, (int)(pk.x & 31u), (int)(pk.x >> 5), __uint_as_float(pk.y), cn);
+                        constexpr bool kHyb = PF_HYBRID_W != 0; const bool gw_row = kHyb && (k & 1);
+                        Aat(r, c) = warp_finish_fast<F32>(b0[k - h].x, b0[k - h].y, b1[k - h].x, b1[k - h].y, (int)(pk.x & 31u), (int)(pk.x >> 5), gw_row ? wq[(k - h) >> 1] : __uint_as_float(pk.y), cn);
                     }
                 }
             }
