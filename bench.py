@@ -540,7 +540,7 @@ def main():
                        # count the bytes of what the launches' blocks processed (alg_bytes_run), frac_full_canvas SURVEY 8d's bytes for EVERY tile
                        # of every canvas, roofline.traffic / frac_delivered what moved
                        **canvas_shares(m)},
-            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0, window_key(K, W, PRE, args.no_cull)),
+            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0 and N == 1, window_key(K, W, PRE, args.no_cull)),
             # the same bytes over the whole step instead of the launches bracketed by events: launches run back to back (gap 0 in the
             # rocprofv3 trace), so a step IS a launch, and an event pair costs the launch it brackets several us (N = 1 only)
             "roofline_per_step": None,

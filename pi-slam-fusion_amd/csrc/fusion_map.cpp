@@ -1092,6 +1092,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             // blocks out.  Level 0 with the blocks' own need test (k_levels, need_r0): the same rule evaluated here from the rendered cells'
             // row bitmaps -- exactly, for the launches that are bracketed by events (10 us of host time), through the level-1 bitmap otherwise.
             double run_share[kMaxLevels];
+            int exact_r0 = 0;
             for (int i = 0; i < kMaxLevels; i++) run_share[i] = 1.0;
             if ((sharded || culled_any) && !cells_overflow) {
                 const int BHr = level_block_rows(lay_.f32 != 0);
@@ -1101,19 +1102,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                     double run = 0;
                     const int r0 = i == 0 && need_n_tmp[1] > 0 ? level0_need_reach(lay_, table_args ? tx * ty : 0, nrect[0]) : 0;
                     if (i == 0 && r0 > 0 && prof_would(K_LEVEL0) && cell_rows_.size() == (size_t)4 * ty) {
-                        typedef unsigned __int128 u128;
-                        for (int gy = 0; gy < nby; gy++) {
-                            const int y0 = std::max(C[0].y0 + gy * BHr - r0, 0) >> 6, y1 = std::min(C[0].y0 + gy * BHr + BHr - 1 + r0, crows - 1) >> 6;
-                            u128 rowsum = 0;
-                            for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
-                            if (!rowsum) continue;
-                            for (int gx = 0; gx < nbx; gx++) {
-                                const int x0 = std::max(C[0].x0 + gx * 64 - r0, 0) >> 6, x1 = std::min(C[0].x0 + gx * 64 + 63 + r0, ccols - 1) >> 6;
-                                if (x0 > x1) continue;
-                                const u128 m = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
-                                run += (rowsum & m) != 0;
-                            }
-                        }
+                        exact_r0 = r0;                              // counted exactly AFTER the launch is out (below): ~50 us of host time that must not delay it
+                        run = blocks_run0;
                     } else if (i == 0) run = blocks_run0;
                     else if (need_n_tmp[i] > 0) { for (int w = 0; w < (need_n_tmp[i] + 31) / 32; w++) run += __builtin_popcount(need_tmp_[i][w]); }
                     else {
@@ -1143,6 +1133,32 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             if (table_args) { cur.table_args = table_tmp_.data(); cur.table_n = tx * ty; }
             for (int i = 1; i < L; i++) { cur.need_n[i] = need_n_tmp[i]; if (need_n_tmp[i] > 0) std::memcpy(cur.need_bits[i], need_tmp_[i], sizeof(uint32_t) * (size_t)((need_n_tmp[i] + 31) / 32)); }
             if (!launch_pipeline(&cur, &a, src)) return false;
+            if (exact_r0 > 0 && prof_on_ && !prof_pending_.empty()) {
+                // this launch is bracketed by events: replace the level-0 job's estimated run share in its record by the exact one (the blocks' own
+                // need rule, k_levels need_r0, from the rendered cells' row bitmaps) -- now that the launch is on its way
+                typedef unsigned __int128 u128;
+                const int BHr = level_block_rows(lay_.f32 != 0), r0 = exact_r0;
+                const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+                // (the column masks once per launch, one AND per block: ~8 us for cfg-A's 7072 blocks)
+                static thread_local std::vector<u128> colmask;
+                colmask.assign((size_t)std::max(nbx, 0), 0);
+                for (int gx = 0; gx < nbx; gx++) {
+                    const int x0 = std::max(C[0].x0 + gx * 64 - r0, 0) >> 6, x1 = std::min(C[0].x0 + gx * 64 + 63 + r0, ccols - 1) >> 6;
+                    if (x0 <= x1) colmask[(size_t)gx] = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
+                }
+                long run = 0;
+                for (int gy = 0; gy < nby; gy++) {
+                    const int y0 = std::max(C[0].y0 + gy * BHr - r0, 0) >> 6, y1 = std::min(C[0].y0 + gy * BHr + BHr - 1 + r0, crows - 1) >> 6;
+                    u128 rowsum = 0;
+                    for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
+                    if (!rowsum) continue;
+                    const uint64_t lo = (uint64_t)rowsum, hi = (uint64_t)(rowsum >> 64);
+                    for (int gx = 0; gx < nbx; gx++) run += ((lo & (uint64_t)colmask[(size_t)gx]) | (hi & (uint64_t)(colmask[(size_t)gx] >> 64))) != 0;
+                }
+                const double n0 = owned_tiles * kElePixels * kElePixels, tile_bytes0 = n0 * (4 + E) + (L == 1 ? n0 / 4 * (4 + E) : 0);
+                const double share = std::min(1.0, run * 64.0 * BHr / std::max(1.0, n0));
+                prof_pending_.back().bytes_run += tile_bytes0 * (share - run_share[0]);
+            }
         } else {
         // fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
         // Level i of frame f runs after level i-1 of frame f (GW_i, event) and, by stream order, after level i of
