@@ -185,3 +185,31 @@ def test_cull_with_seven_bands_single_pixel_cells(pf, orc, force_float):
     assert g.culled_cells() > 100 and g.culled_tiles() > 10, (g.culled_cells(), g.culled_tiles())
     assert compare_maps(g, o) == []
     g.close()
+
+
+def test_run_bytes_follow_the_cull(pf):
+    """Round 5: pf_profile_read_run hands out, next to SURVEY 8d's bytes of every canvas tile, the bytes of the part of
+    the canvases the timed launches' blocks PROCESSED.  With the cull off the two are equal; with it on the run bytes are smaller, never
+    below the frames read once, and the full-canvas bytes do not move (the denominator of bench.py's roofline.frac is the same time)."""
+    wl = workloads()
+    poses = sortie(60)
+    res = {}
+    for cull in (False, True):
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, fused=1, scale=2.5)
+        m.set_cull(cull)
+        assert m.prepare(wl.IDENTITY_PLANE, CAM, poses[:12])
+        for k in range(20):
+            assert m.feed(frame(k), poses[k])
+        m.sync(); m.profile_reset(); m.profile_enable(1)
+        for k in range(20, 60):
+            assert m.feed(frame(k), poses[k])
+        m.sync()
+        p = m.profile_read()["level0_fused"]
+        res[cull] = (p["alg_bytes"], p["alg_bytes_run"], p["launches"], m.culled_tiles() + m.culled_cells())
+        m.close()
+    (full0, run0, n0, c0), (full1, run1, n1, c1) = res[False], res[True]
+    assert n0 == n1 == 40 and c0 == 0 and c1 > 0
+    assert run0 == full0                                   # nothing left out: every block of every canvas ran
+    assert full1 == full0                                  # SURVEY 8d's numerator ignores the cull
+    frames_read = 40 * 640 * 480 * 3
+    assert frames_read < run1 < 0.9 * full1, (run1, full1)
