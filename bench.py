@@ -21,7 +21,10 @@ per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
 gets per GPU is the `host_feed` record of the same line (pf_feed with its 36 MB H2D copy inside: PCIe-bound, ~1500 keyframes/s).
 
 Rank 0 prints ONE JSON line (contract in the task statement), including
-  roofline     : dominant kernel, algorithmic bytes of what its launches processed / HIP-event time on the map's stream
+  roofline     : dominant kernel; `achieved` / `frac` = SURVEY 8d's algorithmic bytes of the part of the canvases its timed launches
+                 PROCESSED (the cull leaves blocks out: pf_profile_read_run) / HIP-event time on the map's stream; `frac_full_canvas` = the same
+                 with the bytes of every canvas tile (what rounds 1-4 printed as `frac`); `traffic` / `frac_delivered` = HBM bytes from the PMC
+                 passes of exactly this window (profiles/pmc_traffic.json, tools/profile_windows.sh), null for a window without a pass
   cpu_baseline : the oracle (CPU port of MultiBandMap2DCPU) timed on a bounded sample.
 Every leg after the timed GPU region is guarded: a failure there becomes {"error": ...} inside
 the line and never loses the GPU measurement.
