@@ -26,6 +26,9 @@
 #ifndef PF_EXPERIMENTS
 #define PF_EXPERIMENTS 0
 #endif
+#ifndef PF_ROWTAB            // A/B build switch: the row terms of the coordinates from a per-block LDS table (level3_block, deferred stage A)
+#define PF_ROWTAB 0
+#endif
 #ifndef PF_HYBRID_W          // A/B build switch: see level3_block, deferred stage A
 #define PF_HYBRID_W 0
 #endif
@@ -976,6 +979,9 @@ __global__ __launch_bounds__(LNT) void k_level(LevelOffsets lay, LevelArgs g, Fu
 //      serves the four pyrUp parities; one tile-table entry and two 8-byte weight loads per
 //      thread, prefetched after A
 // LDS: A + B only (54 KB fp32 / 40.6 KB int16).
+// ILP (stage A of a level-0 block): 0 = every row's coordinates, weight and loads first, every bilinear sum last, with the fractions and the
+// weight parked in the pixel's LDS slot meanwhile (blocks that map strictly inside the frame; the fp32 product form since round 5);
+// 2 / 3 = fetch, fetch(, fetch) | finish, finish(, finish) per step (the int16 product form: 2; every block that does not map inside).
 // diagnostic build only (PF_STAMP=1, tools/stamp_phases.py): s_memtime at the phase boundaries of a workgroup, written by
 // its first lane to a buffer nothing else reads.  The stamped kernel is a separate instantiation; the product kernel
 // carries no stamp code.
@@ -1219,6 +1225,21 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
             // bilinear sum.  All 2 x 6 loads of a thread are in flight while it computes the coordinates of its later rows, and a wave
             // waits for memory once per block instead of once per step (rounds 2-4: fetch, fetch, fetch | finish, finish, finish per step;
             // the straight-line form of that loop was +22 % per wave but needed 94-123 VGPRs for the parked state, r02).
+            // A/B (-DPF_ROWTAB=1): the terms of a pixel's coordinates that depend on its canvas row and 64-wide coordinate block only --
+            // X0 = (M0 xb + M1 y) + M2, Y0, W0: nine fp64 operations per pixel -- from a table of 39 rows x 3 blocks x 3 terms that 351 threads
+            // fill once per workgroup (in the LDS behind A, free until stage B), at the price of one more barrier and two LDS reads per pixel
+            constexpr bool kRowTab = PF_ROWTAB != 0;
+            double (*rowtab)[3][4] = reinterpret_cast<double (*)[3][4]>(tail);
+            const int xb0 = ax0 & ~63;
+            if constexpr (kRowTab) {
+                static_assert(!kRowTab || sizeof(double) * LAH * 3 * 4 <= (size_t)kTail, "row table fits behind A");
+                if (tid < LAH * 9) {
+                    const int r = tid / 9, e = tid - r * 9, kx = e / 3, w = e - kx * 3;
+                    const double xb = (double)(xb0 + 64 * kx), y = (double)(ay0 + r);
+                    rowtab[r][kx][w] = wa.M[3 * w] * xb + wa.M[3 * w + 1] * y + wa.M[3 * w + 2];
+                }
+                lds_barrier();
+            }
             if (r0 < RS) {
                 constexpr int NR = (LAH + RS - 1) / RS;
                 typedef uint32_t u2 __attribute__((ext_vector_type(2), aligned(1)));
@@ -1244,7 +1265,13 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                         if (k >= LAH - (RS - 1) * NR && __builtin_amdgcn_ballot_w64(has) == 0) continue;
                         const int r = has ? rbase + k : rbase;
                         const int y = ay0 + r;
-                        const double X0 = col.m0xb + wa.M[1] * y + wa.M[2], Y0 = col.m3xb + wa.M[4] * y + wa.M[5], W0 = col.m6xb + wa.M[7] * y + wa.M[8];
+                        double X0, Y0, W0;
+                        if constexpr (kRowTab) {
+                            const double* t = rowtab[r][(((ax0 + c) & ~63) - xb0) >> 6];
+                            X0 = t[0]; Y0 = t[1]; W0 = t[2];
+                        } else {
+                            X0 = col.m0xb + wa.M[1] * y + wa.M[2]; Y0 = col.m3xb + wa.M[4] * y + wa.M[5]; W0 = col.m6xb + wa.M[7] * y + wa.M[8];
+                        }
                         const double W = W0 + col.m6x1, xn = X0 + col.m0x1, yn = Y0 + col.m3x1;
                         // (a lane past the tile re-does its first row: its seed is then five rows off, and its result is not stored)
                         Wn = (k > 0 && seed) ? rcp_seeded(W, Wn) : rcp_mid_range(W);
@@ -1747,7 +1774,7 @@ __global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 |
         // with need rectangles (a shard, or tiles culled) whole bands of the grid exit at once: contiguous runs per XCD would leave some
         // XCDs without work, so the blocks are dealt round robin instead (PF_RECT_ORDER=1 keeps the runs, for A/B)
         const int rr = kExp ? rect_runs : 0;                  // PF_RECT_ORDER (A/B): 1 XCD runs even with rectangles, 2 round robin always, >= 3 runs of 4 / 8 / 16 blocks
-        bb = rr >= 3 ? xcd_chunks(b, nblk, 1 << (rr - 1)) : ((J.nrect && !rr) || rr == 2) ? b : xcd_order(b, nblk);
+        bb = rr >= 3 ? xcd_chunks(b, nblk, 1 << (rr >= 3 ? rr - 1 : 0)) : ((J.nrect && !rr) || rr == 2) ? b : xcd_order(b, nblk);
     }
     // the newest frame's tile table arrived in the kernel arguments: one workgroup stores it where the launches that
     // carry this frame's upper levels will read it (kernel boundaries order that)
