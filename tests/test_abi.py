@@ -113,3 +113,20 @@ def test_weight_map_helpers(pf):
     inv = (1.0 / d.astype(np.float64)).astype(np.float32)                 # Point3_ operator/ multiplies by (1./b)
     assert np.array_equal(b, inv[:, None] * src)
     assert pf.lib().pf_mul_weight_map(None, a.ctypes.data, 10) == 0
+
+
+def test_product_library_carries_the_product_kernels_only():
+    """the forms of the level kernel that were measured and not adopted (rolling strips, LDS patch, 64x28 / 64x64 blocks,
+    the other row loops, stamped instantiations) live in libpifusion_exp.so (-DPF_EXPERIMENTS=1); libpifusion.so carries four instantiations
+    of k_levels -- {fp32 deferred stage A, int16 two rows per step} x {weight computed, weight plane gathered}."""
+    import re
+    here = os.path.join(ROOT, "pi-slam-fusion_amd")
+    prod = open(os.path.join(here, "libpifusion.so"), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"_ZN2pf8k_levelsIL[0-9A-Za-z_]+?EEEvNS_10LevelBatchE", prod))
+    assert len(names) == 4, names
+    assert b"_ZN2pf8k_stripsI" not in prod
+    exp_path = os.path.join(here, "libpifusion_exp.so")
+    if os.path.exists(exp_path):
+        exp = open(exp_path, "rb").read()
+        assert b"_ZN2pf8k_stripsI" in exp
+        assert len(set(re.findall(rb"_ZN2pf8k_levelsIL[0-9A-Za-z_]+?EEEvNS_10LevelBatchE", exp))) > 10
