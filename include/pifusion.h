@@ -109,6 +109,15 @@ int     pf_save(pf_map* m, const char* filename);
 /* The file leg of save() alone: cv::imwrite(filename, result), MultiBandMap2DCPU.cpp:841.  8-bit BGR in,
  * PNG (8-bit RGB, deflate) when the name ends in .png/.PNG, binary PPM (P6) otherwise.  No device needed. */
 int     pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols);
+/* Input side of the file driver: the reference reads each keyframe with cv::imread(imgfile), backup/map2dfusion.cpp:129-132
+ * (8-bit BGR, EXIF orientation ignored as OpenCV 2.4.9 does).  JPEG (baseline, extended and progressive Huffman; grey or
+ * YCbCr/RGB; libjpeg's default ISLOW IDCT, fancy upsampling and colour tables, byte-equal to libjpeg-turbo) and binary PPM.
+ * pf_image_info fills rows/cols; pf_read_image decodes into rows*cols*3 bytes.  pf_jpeg_* take the stream from memory.
+ * Host code; no device needed.  0 + pf_last_error() on anything unsupported or malformed.                              */
+int     pf_image_info(const char* filename, int* rows, int* cols);
+int     pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols);
+int     pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components);
+int     pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols);
 /* save() without the file: whole-mosaic collapse into caller memory.  Call
  * with bgr=NULL to query rows/cols/origin tile.                            */
 int     pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);

@@ -5,9 +5,10 @@
 // size the grid with the first PrepareFrameNum frames, then feed while `queueSize() < 2`, paced at
 // Video.fps, and save() to Map.File2Save at the end.
 //
-// Header-only over include/pifusion/Map2D.h.  The reference decodes frames with cv::imread; this
-// build has no image codec, so binary PPM (P6) frames are read natively and any other format goes
-// through a decoder hook (`DroneMapDataset::decoder`) -- plug cv::imread in there.
+// Header-only over include/pifusion/Map2D.h.  The reference decodes frames with cv::imread; here
+// <name>.jpg goes through the library's own JPEG decoder (pf_read_image: libjpeg's default decode byte
+// for byte, csrc/jpeg_decode.cpp), <name>.ppm (binary P6) is read when there is no .jpg, and a decoder
+// hook (`DroneMapDataset::decoder`) takes over the .jpg when set -- cv::imread plugs in there.
 #ifndef PIFUSION_TESTSYSTEM_H
 #define PIFUSION_TESTSYSTEM_H
 #include "Map2D.h"
@@ -123,7 +124,7 @@ class DroneMapDataset {
 public:
     Config      cfg;
     std::string datapath;
-    // called for frames that are not PPM (the reference: cv::imread(imgfile)); returns false when it cannot decode
+    // when set, decodes <name>.jpg instead of pf_read_image (the reference: cv::imread(imgfile)); returns false when it cannot
     std::function<bool(const std::string& file, OwnedImage& out)> decoder;
 
     bool open(const std::string& path)
@@ -145,11 +146,21 @@ public:
         double p[7];
         for (int i = 0; i < 7; i++) if (!(ifs >> p[i])) return false;
         const std::string base = datapath + "/rgb/" + name;
-        if (!read_ppm_bgr(base + ".ppm", frame.first)) {
-            if (!decoder || !decoder(base + ".jpg", frame.first)) return false;
-        }
+        if (!(decoder ? decoder(base + ".jpg", frame.first) : read_native(base + ".jpg", frame.first)) &&
+            !read_ppm_bgr(base + ".ppm", frame.first)) return false;
         frame.second = pi::SE3d(p[0], p[1], p[2], p[3], p[4], p[5], p[6]);      // SE3 stream order x y z qx qy qz qw (SE3.h:112-117)
         return true;
+    }
+    // cv::imread(file) through the library: JPEG (or PPM) -> BGR8
+    static bool read_native(const std::string& file, OwnedImage& out)
+    {
+        int rows = 0, cols = 0;
+        FILE* f = std::fopen(file.c_str(), "rb");                      // a dataset without this .jpg is not an error yet: the .ppm is tried next
+        if (!f) return false;
+        std::fclose(f);
+        if (!pf_image_info(file.c_str(), &rows, &cols)) return false;
+        out.create(rows, cols, PF_8UC3);
+        return pf_read_image(file.c_str(), out.data, rows, cols) != 0;
     }
 private:
     std::shared_ptr<std::ifstream> in_;

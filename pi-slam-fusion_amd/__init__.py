@@ -84,6 +84,10 @@ def lib():
     L.pf_save.argtypes = [vp, C.c_char_p]
     L.pf_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
     L.pf_write_image.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    L.pf_image_info.argtypes = [C.c_char_p, ip, ip]
+    L.pf_read_image.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
+    L.pf_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, ip, ip, ip]
+    L.pf_jpeg_decode_bgr.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int]
     L.pf_num_levels.argtypes = [vp]
     L.pf_pyramid_type.argtypes = [vp]
     L.pf_grid.argtypes = [vp, ip, dp]
@@ -203,6 +207,29 @@ def write_image(filename, bgr):
     """cv::imwrite leg of save() (MultiBandMap2DCPU.cpp:841): HxWx3 BGR uint8 -> .png / .ppm"""
     a = np.ascontiguousarray(bgr, dtype=np.uint8)
     return bool(lib().pf_write_image(filename.encode(), a.ctypes.data, a.shape[0], a.shape[1]))
+
+
+def read_image(filename):
+    """cv::imread(filename) of the file driver (backup/map2dfusion.cpp:129-132): JPEG or binary PPM -> HxWx3 BGR uint8.
+    Raises on a file the library cannot read (there is no other decoder behind it)."""
+    L = lib(); r = C.c_int(); c = C.c_int()
+    if not L.pf_image_info(filename.encode(), C.byref(r), C.byref(c)):
+        raise RuntimeError("read_image: %s" % L.pf_last_error().decode())
+    out = np.empty((r.value, c.value, 3), np.uint8)
+    if not L.pf_read_image(filename.encode(), out.ctypes.data, r.value, c.value):
+        raise RuntimeError("read_image: %s" % L.pf_last_error().decode())
+    return out
+
+
+def decode_jpeg(data):
+    """cv::imdecode-style entry: the bytes of a JPEG stream -> HxWx3 BGR uint8 (libjpeg's default decode, byte for byte)."""
+    L = lib(); b = bytes(data); r = C.c_int(); c = C.c_int(); k = C.c_int()
+    if not L.pf_jpeg_info(b, len(b), C.byref(r), C.byref(c), C.byref(k)):
+        raise ValueError("decode_jpeg: %s" % L.pf_last_error().decode())
+    out = np.empty((r.value, c.value, 3), np.uint8)
+    if not L.pf_jpeg_decode_bgr(b, len(b), out.ctypes.data, r.value, c.value):
+        raise ValueError("decode_jpeg: %s" % L.pf_last_error().decode())
+    return out
 
 
 def tile_owner(opt, ix, iy):

@@ -1,5 +1,6 @@
 // c_api.cpp -- extern "C" surface of libpifusion.so (include/pifusion.h).
 #include "dist.hpp"
+#include "jpeg_decode.hpp"
 #include <cstdlib>
 #include <cmath>
 #include <cstdio>
@@ -73,6 +74,27 @@ int pf_sync(pf_map* m) { return m && m->impl.sync(); }
 int pf_save(pf_map* m, const char* filename) { return m && filename && m->impl.save(filename); }
 int pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols)
 { return filename && bgr && rows > 0 && cols > 0 && pf::write_image_file(filename, bgr, rows, cols); }
+int pf_image_info(const char* filename, int* rows, int* cols)
+{
+    if (!filename || !rows || !cols) return 0;
+    std::vector<uint8_t> b;
+    if (!pf::read_file_bytes(filename, b)) return 0;
+    if (b.size() >= 2 && b[0] == 0xFF && b[1] == 0xD8) return pf::jpeg_info(b.data(), b.size(), rows, cols, nullptr);
+    std::vector<uint8_t> px;                                                  // PPM: the header is all there is to parse
+    return pf::read_image_file(filename, px, rows, cols);
+}
+int pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols)
+{
+    if (!filename || !bgr) return 0;
+    std::vector<uint8_t> px; int r = 0, c = 0;
+    if (!pf::read_image_file(filename, px, &r, &c)) return 0;
+    if (r != rows || c != cols) { pf::set_error("pf_read_image: the buffer does not have the image's size"); return 0; }
+    std::memcpy(bgr, px.data(), px.size());
+    return 1;
+}
+int pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components) { return pf::jpeg_info(data, len, rows, cols, components); }
+int pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols)
+{ return rows > 0 && cols > 0 && pf::jpeg_decode_bgr(data, len, bgr, rows, cols, (size_t)cols * 3); }
 int pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return m && rows && cols && tx0 && ty0 && m->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
 

@@ -60,7 +60,10 @@ class DroneMapDataset:
             if os.path.exists(base + ext):
                 if ext == ".npy":
                     return np.load(base + ext), pose
-                from PIL import Image
+                if ext in (".jpg", ".ppm"):
+                    from . import read_image                               # the library's own decoder (csrc/jpeg_decode.cpp)
+                    return read_image(base + ext), pose
+                from PIL import Image                                      # .png frames: not a format the reference's datasets use
                 rgb = np.asarray(Image.open(base + ext).convert("RGB"))
                 return np.ascontiguousarray(rgb[:, :, ::-1]), pose
         raise FileNotFoundError(base + ".jpg")

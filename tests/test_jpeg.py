@@ -1,0 +1,188 @@
+"""Row f3 of SURVEY 8, input side: the reference reads each keyframe with cv::imread(imgfile) (backup/map2dfusion.cpp:129-132),
+which for .jpg is libjpeg's default decode.  csrc/jpeg_decode.cpp restates it; these tests hold it byte-equal to
+libjpeg-turbo -- against the committed vectors (tests/golden/jpeg_vectors.npz, made by tests/golden/make_jpeg_vectors.py)
+and, where Pillow is importable, live on streams encoded on the spot by Pillow and by tests/jpeg_enc.py.  Host code: no GPU."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import jpeg_enc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def vectors():
+    z = np.load(os.path.join(HERE, "golden", "jpeg_vectors.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return [(meta["cases"][i], bytes(z["stream%02d" % i]), z["rgb%02d" % i]) for i in range(len(meta["cases"]))]
+
+
+def picture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    a = (np.sin(x / 5.0)[..., None] * 80 + 128 + rng.normal(0, 25, (h, w, 3))) * (0.5 + 0.5 * ((x // 8 + y // 8) % 2))[..., None]
+    return a.clip(0, 255).astype(np.uint8)
+
+
+def test_golden_vectors_decode_byte_equal(pf):
+    vs = vectors()
+    assert len(vs) >= 26
+    for case, stream, rgb in vs:
+        got = pf.decode_jpeg(stream)
+        assert got.shape == rgb.shape, case
+        assert np.array_equal(got[:, :, ::-1], rgb), case            # BGR out, as cv::imread returns it
+
+
+def test_vectors_cover_the_stream_shapes():
+    cases = [c for c, _, _ in vectors()]
+    assert any(c.get("progressive") for c in cases) and any(c.get("optimize") for c in cases)
+    assert any(c.get("restart_marker_blocks") or c.get("restart") for c in cases)
+    assert any(c.get("mode") == "L" or c.get("grey") for c in cases)
+    assert any(c.get("interleaved") is False for c in cases) and any(c.get("long_codes") for c in cases)
+    assert {tuple(map(tuple, c["sampling"]))[0] for c in cases if "sampling" in c} >= {(1, 2), (4, 1), (2, 2), (1, 1), (2, 1), (1, 4)}
+    assert {c["subsampling"] for c in cases if "subsampling" in c} == {0, 1, 2}
+
+
+def test_info_and_file_entry_points(pf, tmp_path):
+    import ctypes as C
+    case, stream, rgb = vectors()[0]
+    L = pf.lib(); r = C.c_int(); c = C.c_int(); k = C.c_int()
+    assert L.pf_jpeg_info(stream, len(stream), C.byref(r), C.byref(c), C.byref(k)) == 1
+    assert (r.value, c.value, k.value) == (rgb.shape[0], rgb.shape[1], 3)
+    p = str(tmp_path / "a.jpg")
+    open(p, "wb").write(stream)
+    assert np.array_equal(pf.read_image(p)[:, :, ::-1], rgb)
+    # the same entry point reads the binary PPM the file driver also accepts
+    q = str(tmp_path / "a.ppm")
+    open(q, "wb").write(b"P6\n# comment\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]) + rgb.tobytes())
+    assert np.array_equal(pf.read_image(q)[:, :, ::-1], rgb)
+    # a buffer of the wrong size is refused, not overrun
+    small = np.zeros((2, 2, 3), np.uint8)
+    assert L.pf_read_image(p.encode(), small.ctypes.data, 2, 2) == 0 and b"size" in L.pf_last_error()
+    assert L.pf_jpeg_decode_bgr(stream, len(stream), small.ctypes.data, 2, 2) == 0
+    with pytest.raises(RuntimeError):
+        pf.read_image(str(tmp_path / "missing.jpg"))
+
+
+def test_malformed_and_unsupported_streams_fail_loudly(pf):
+    _, stream, rgb = vectors()[0]
+    for bad, what in [(b"", "SOI"), (b"\x89PNG\r\n\x1a\n", "SOI"), (b"\xff\xd8\x00\x00", "no image"), (stream[:20], "")]:
+        with pytest.raises(ValueError) as e:
+            pf.decode_jpeg(bad)
+        assert what in str(e.value)
+    sof = stream.index(b"\xff\xc0")
+    twelve = bytearray(stream); twelve[sof + 4] = 12
+    with pytest.raises(ValueError, match="8-bit"):
+        pf.decode_jpeg(bytes(twelve))
+    arith = bytearray(stream); arith[sof + 1] = 0xC9
+    with pytest.raises(ValueError, match="arithmetic"):
+        pf.decode_jpeg(bytes(arith))
+    four = bytearray(stream); four[sof + 9] = 4
+    with pytest.raises(ValueError, match="component"):
+        pf.decode_jpeg(bytes(four))
+    # more than ten blocks per MCU in an interleaved scan: libjpeg refuses it too
+    with pytest.raises(ValueError, match="interleaved"):
+        pf.decode_jpeg(jpeg_enc.encode(picture(16, 16, 1), ((2, 2), (2, 2), (2, 2))))
+    with pytest.raises(ValueError, match="fractional"):
+        pf.decode_jpeg(jpeg_enc.encode(picture(16, 16, 1), ((2, 1), (1, 1), (1, 1))).replace(b"\x01\x21\x00\x02\x11", b"\x01\x31\x00\x02\x21"))
+
+
+def test_truncated_stream_decodes_what_is_there(pf):
+    """libjpeg warns ("premature end of data segment") and returns the rows it has, the rest from zero coefficients"""
+    case, stream, rgb = [v for v in vectors() if v[0]["size"] == [40, 56] and not v[0].get("progressive")][0]
+    cut = stream[: len(stream) * 2 // 3]
+    got = pf.decode_jpeg(cut)[:, :, ::-1]
+    assert got.shape == rgb.shape
+    assert np.array_equal(got[:8], rgb[:8])                                # the first MCU rows were complete
+    assert not np.array_equal(got, rgb)
+    # without the EOI marker but with all the data: the same picture
+    assert np.array_equal(pf.decode_jpeg(stream[:-2])[:, :, ::-1], rgb)
+
+
+def test_live_against_pillow(pf):
+    Image = pytest.importorskip("PIL.Image")
+    n = 0
+    for (h, w) in [(1, 1), (3, 5), (16, 16), (17, 33), (64, 48), (67, 130), (200, 3), (4, 100)]:
+        a = picture(h, w, h * 1000 + w)
+        for sub in (0, 1, 2):
+            for q in (20, 75, 100):
+                for opts in ({}, {"optimize": True}, {"progressive": True}, {"restart_marker_blocks": 3}, {"restart_marker_rows": 1, "progressive": True}):
+                    for mode in ("RGB", "L"):
+                        b = io.BytesIO()
+                        Image.fromarray(a).convert(mode).save(b, "JPEG", quality=q, subsampling=sub, **opts)
+                        ref = np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))
+                        assert np.array_equal(pf.decode_jpeg(b.getvalue())[:, :, ::-1], ref), (h, w, sub, q, opts, mode)
+                        n += 1
+    assert n == 8 * 3 * 3 * 5 * 2
+
+
+def test_live_other_sampling_factors_against_pillow(pf):
+    Image = pytest.importorskip("PIL.Image")
+    samplings = [((1, 1), (1, 1), (1, 1)), ((2, 2), (1, 1), (1, 1)), ((2, 1), (1, 1), (1, 1)), ((1, 2), (1, 1), (1, 1)), ((4, 1), (1, 1), (1, 1)),
+                 ((4, 2), (1, 1), (1, 1)), ((1, 4), (1, 1), (1, 1)), ((2, 2), (2, 1), (1, 2)), ((2, 2), (1, 2), (2, 1)), ((1, 1), (2, 2), (1, 1))]
+    variants = [{}, {"interleaved": False}, {"restart": 2}, {"long_codes": True}, {"q16": True, "q": 3}, {"colour": "rgb"}, {"jfif": False},
+                {"interleaved": False, "restart": 3, "long_codes": True}]
+    for (h, w) in [(1, 1), (9, 7), (33, 47), (40, 3), (3, 40)]:
+        a = picture(h, w, 7 * h + w)
+        for samp in samplings:
+            for kw in variants:
+                b = jpeg_enc.encode(a, samp, **kw)
+                ref = np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+                assert np.array_equal(pf.decode_jpeg(b)[:, :, ::-1], ref), (h, w, samp, kw)
+        for kw in ({}, {"restart": 1}, {"long_codes": True}):
+            b = jpeg_enc.encode(a[..., 1], ((2, 2),), **kw)
+            assert np.array_equal(pf.decode_jpeg(b)[:, :, ::-1], np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))), (h, w, kw)
+
+
+def test_dataset_reader_uses_the_library_for_jpg(pf, tmp_path):
+    """DroneMapDataset.load: <dir>/rgb/<name>.jpg through pf.read_image (no Pillow in the product path)"""
+    import importlib
+    ds = importlib.import_module("pi_slam_fusion_amd.dataset")
+    case, stream, rgb = vectors()[3]
+    d = tmp_path / "ds"
+    os.makedirs(d / "rgb")
+    open(d / "config.cfg", "w").write("Plane = 0 0 0 0 0 0 1\nCamera.Paraments = [%d %d 50 50 %g %g]\n" % (rgb.shape[1], rgb.shape[0], rgb.shape[1] / 2, rgb.shape[0] / 2))
+    open(d / "trajectory.txt", "w").write("000000 0 0 100 0 0 0 1\n")
+    open(d / "rgb" / "000000.jpg", "wb").write(stream)
+    img, pose = ds.DroneMapDataset(str(d)).load(0)
+    assert np.array_equal(img[:, :, ::-1], rgb) and pose == [0, 0, 100, 0, 0, 0, 1]
+
+
+def test_cpp_dataset_reader_decodes_jpg_frames(pf, tmp_path):
+    """the C++ file driver's obtainFrame: <name>.jpg through pf_read_image, <name>.ppm when there is no .jpg, and the
+    decoder hook's place taken by the library (TestSystem.h)"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "dataset_frames")
+    lib = os.path.join(root, "pi-slam-fusion_amd")
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(HERE, "cpp", "dataset_frames.cpp"), "-o", exe,
+                           "-L" + lib, "-l:libpifusion.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    vs = [v for v in vectors() if v[0]["size"] == [29, 37]][:3] + [v for v in vectors() if v[0]["size"] == [33, 17]][:1]
+    d = tmp_path / "ds"
+    os.makedirs(d / "rgb")
+    open(d / "config.cfg", "w").write("Plane = 0 0 0 0 0 0 1\n")
+    with open(d / "trajectory.txt", "w") as f:
+        for k in range(len(vs) + 1):
+            f.write("%06d 0 0 %d 0 0 0 1\n" % (k, 100 + k))
+    want = []
+    for k, (_, stream, rgb) in enumerate(vs):
+        open(d / "rgb" / ("%06d.jpg" % k), "wb").write(stream)
+        want.append(rgb)
+    k = len(vs)                                                       # one PPM frame after the JPEGs
+    open(d / "rgb" / ("%06d.ppm" % k), "wb").write(b"P6\n%d %d\n255\n" % (vs[0][2].shape[1], vs[0][2].shape[0]) + vs[0][2].tobytes())
+    want.append(vs[0][2])
+    r = subprocess.run([exe, str(d)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=60)
+    assert r.returncode == 0, r.stdout.decode()
+    lines = r.stdout.decode().split("\n")
+    assert "frames %d" % len(want) in lines
+
+    def fnv(a):
+        h = 1469598103934665603
+        for b in np.ascontiguousarray(a[:, :, ::-1]).tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for k, rgb in enumerate(want):
+        assert lines[k] == "%d %d %d %d" % (k, rgb.shape[0], rgb.shape[1], fnv(rgb)), (k, lines[k])

@@ -21,6 +21,8 @@ def write_dataset(tmp, cam, poses, frames, plane, ppm=True, extra=""):
     with open(os.path.join(tmp, "trajectory.txt"), "w") as f:
         for k, p in enumerate(poses):
             f.write("%06d %s\n" % (k, " ".join(repr(float(x)) for x in p)))
+            if ppm is None:
+                continue                                   # the caller writes the frames itself
             if ppm:
                 with open(os.path.join(tmp, "rgb", "%06d.ppm" % k), "wb") as g:
                     g.write(b"P6\n%d %d\n255\n" % (frames[k].shape[1], frames[k].shape[0]))
@@ -84,5 +86,42 @@ def test_dataset_replay_equals_oracle(pf, orc, tmp_path, thread, ff):
     out2 = str(tmp_path / "py.png")
     cmd = [sys.executable, os.path.join(ROOT, "tools", "replay.py"), d, "--prepare", "3", "--thread", str(thread), "--out", out2]
     r = subprocess.run(cmd + (["--float"] if ff else []), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    assert np.array_equal(np.asarray(Image.open(out2).convert("RGB"))[:, :, ::-1], ref)
+
+
+@pytest.mark.gpu
+def test_jpeg_dataset_replay_equals_oracle(pf, orc, tmp_path):
+    """The dataset as the reference ships it: rgb/<name>.jpg.  Both file drivers decode the frames with the library
+    (cv::imread's place, backup/map2dfusion.cpp:129-132); the oracle is fed what libjpeg-turbo (Pillow) decodes."""
+    import io
+    from PIL import Image
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(8, seed=77)
+    plane = wl.IDENTITY_PLANE
+    d = str(tmp_path / "ds")
+    write_dataset(d, cam, poses, [None] * len(poses), plane, ppm=None, extra="PrepareFrameNum = 3\nVideo.fps = 0\n")
+    frames = []
+    for k in range(len(poses)):
+        y, x = np.mgrid[0:480, 0:640]
+        a = np.stack([(x * 3 + 40 * k) % 256, (y * 2 + x) % 256, ((x // 16 + y // 16) % 2) * 200 + 20], -1).astype(np.uint8)
+        a = (a.astype(np.int32) + wl.noise_frame(480, 640, 900 + k) // 8).clip(0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", quality=88, subsampling=[2, 1, 0][k % 3], progressive=bool(k & 1))
+        open(os.path.join(d, "rgb", "%06d.jpg" % k), "wb").write(b.getvalue())
+        frames.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))[:, :, ::-1]))
+    ref = oracle_of(orc, cam, poses, frames, plane, 3, 3, 0)
+
+    exe = build_replay(str(tmp_path))
+    out = str(tmp_path / "cpp.png")
+    r = subprocess.run([exe, d, "Map2D.Thread=0", "Map.File2Save=" + out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()
+    assert b"Loaded 3 frames" in r.stdout and b"Fed 5 frames" in r.stdout
+    assert np.array_equal(np.asarray(Image.open(out).convert("RGB"))[:, :, ::-1], ref)
+
+    out2 = str(tmp_path / "py.png")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay.py"), d, "--prepare", "3", "--thread", "0", "--out", out2],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     assert np.array_equal(np.asarray(Image.open(out2).convert("RGB"))[:, :, ::-1], ref)
