@@ -88,13 +88,17 @@ def guarded(fn, *a, **kw):
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
 
+# the sources of the fusion kernels and of the host engine that builds their arguments (the files the PMC numbers depend on); the file
+# driver's image codecs (jpeg_decode.*, jpeg_device.*, image_io.cpp) are not among them
+KERNEL_SOURCES = ("dist.hpp", "fusion_map.hpp", "geometry.hpp", "kernels.hip", "kernels.hpp", "single_band.hip", "strips.inc", "warp_index.hpp")
+
+
 def kernels_sha():
     """Build id of the device code the PMC numbers under profiles/ belong to."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "pi-slam-fusion_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".inc")) and f != "jpeg_decode.hpp":      # the file driver's image codec: host code, not part of any kernel
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in sorted(KERNEL_SOURCES):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -118,6 +118,15 @@ int     pf_image_info(const char* filename, int* rows, int* cols);
 int     pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols);
 int     pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components);
 int     pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols);
+/* The same decode with its back end on the GPU: markers and Huffman on the calling thread, then the coefficients cross PCIe
+ * once and two kernels do libjpeg's dequantise + ISLOW IDCT, fancy upsampling and colour conversion (csrc/jpeg_device.hip),
+ * byte-equal to pf_jpeg_decode_bgr.  dev_bgr: rows*cols*3 bytes of device memory, complete in the order of `hip_stream`
+ * (a hipStream_t, NULL = the default stream); the call returns when the work is queued.                               */
+int     pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream);
+/* Map2D::feed(cv::imread(imgfile), pose) in one call (backup/map2dfusion.cpp:129-135 + Map2DFusion.cpp:313-327): the frame
+ * is decoded straight into HBM on the map's stream and rendered from there (thread=0 maps; a thread=1 map decodes on the
+ * host and queues the pixels as pf_feed does).  Returns what pf_feed returns.                                          */
+int     pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7]);
 /* save() without the file: whole-mosaic collapse into caller memory.  Call
  * with bgr=NULL to query rows/cols/origin tile.                            */
 int     pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);

@@ -119,6 +119,13 @@ public:
         const pf_image v = pifusion::view(img);
         return pf_feed(h_, &v, p) != 0;
     }
+    // feed(cv::imread(file), pose) with the file's bytes instead of its pixels (backup/map2dfusion.cpp:129-135): the JPEG stream is
+    // decoded straight into HBM (Huffman on this thread, IDCT / upsampling / colour on the GPU) and rendered from there
+    template <class SE3> bool feedJpeg(const unsigned char* data, size_t len, const SE3& pose)
+    {
+        double p[7]; pifusion::pose7(pose, p);
+        return pf_feed_jpeg(h_, data, len, p) != 0;
+    }
     // draw(): refresh every tile whose Ischanged flag is set and pass (ix, iy, BGR8 256x256) on.
     // With fuseGoogle() set, `announce` receives what the reference hands to scommand.Call("MapWidget", ...) for every refreshed
     // tile that is not on the rim of the grid (MultiBandMap2DCPU.cpp:744-757): "Map2DUpdate LastTexMat <gpsTL> <gpsBR>".

@@ -135,8 +135,9 @@ public:
         if (!in_->is_open()) { std::cerr << "Can't open file " << (datapath + "/trajectory.txt") << std::endl; return false; }
         return true;
     }
-    // backup/map2dfusion.cpp:122-135
-    bool obtainFrame(std::pair<OwnedImage, pi::SE3d>& frame)
+    // backup/map2dfusion.cpp:122-135.  With `encoded` given (and no decoder hook), a frame that exists as <name>.jpg is handed over
+    // as the file's bytes (frame.first stays empty) for Map2D::feedJpeg to decode on the GPU.
+    bool obtainFrame(std::pair<OwnedImage, pi::SE3d>& frame, std::vector<unsigned char>* encoded = nullptr)
     {
         std::string line;
         if (!in_ || !std::getline(*in_, line)) return false;
@@ -146,10 +147,26 @@ public:
         double p[7];
         for (int i = 0; i < 7; i++) if (!(ifs >> p[i])) return false;
         const std::string base = datapath + "/rgb/" + name;
-        if (!(decoder ? decoder(base + ".jpg", frame.first) : read_native(base + ".jpg", frame.first)) &&
-            !read_ppm_bgr(base + ".ppm", frame.first)) return false;
+        frame.first = OwnedImage();
+        if (encoded) encoded->clear();
+        if (encoded && !decoder && read_bytes(base + ".jpg", *encoded)) { /* decoded by the map */ }
+        else if (!(decoder ? decoder(base + ".jpg", frame.first) : read_native(base + ".jpg", frame.first)) &&
+                 !read_ppm_bgr(base + ".ppm", frame.first)) return false;
         frame.second = pi::SE3d(p[0], p[1], p[2], p[3], p[4], p[5], p[6]);      // SE3 stream order x y z qx qy qz qw (SE3.h:112-117)
         return true;
+    }
+    static bool read_bytes(const std::string& file, std::vector<unsigned char>& out)
+    {
+        FILE* f = std::fopen(file.c_str(), "rb");
+        if (!f) return false;
+        std::fseek(f, 0, SEEK_END);
+        const long n = std::ftell(f);
+        std::fseek(f, 0, SEEK_SET);
+        out.resize(n > 0 ? (size_t)n : 0);
+        const bool ok = n > 0 && std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+        std::fclose(f);
+        if (!ok) out.clear();
+        return ok;
     }
     // cv::imread(file) through the library: JPEG (or PPM) -> BGR8
     static bool read_native(const std::string& file, OwnedImage& out)
@@ -201,12 +218,16 @@ inline int testMap2D(const std::string& datapath, const std::vector<std::string>
     if (svar.GetInt("AutoFeedFrames", 1)) {
         const int fps = svar.GetInt("Video.fps", 100);
         const auto period = std::chrono::microseconds(fps > 0 ? 1000000 / fps : 0);
+        // .jpg frames go to the map as the file's bytes (decoded on the GPU) unless Map2D.DecodeOnHost=1 asks for the reference's order
+        const bool on_device = svar.GetInt("Map2D.DecodeOnHost", 0) == 0;
+        std::vector<unsigned char> encoded;
         for (;;) {                                                     // Map2DFusion.cpp:311-327
             const auto t0 = std::chrono::steady_clock::now();
             if (map->queueSize() < 2) {
                 std::pair<OwnedImage, pi::SE3d> frame;
-                if (!ds.obtainFrame(frame)) break;
-                map->feed(frame.first, frame.second);
+                if (!ds.obtainFrame(frame, on_device ? &encoded : nullptr)) break;
+                if (!encoded.empty()) map->feedJpeg(encoded.data(), encoded.size(), frame.second);
+                else map->feed(frame.first, frame.second);
                 fed++;
             }
             if (fps > 0) std::this_thread::sleep_until(t0 + period);

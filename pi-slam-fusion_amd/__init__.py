@@ -88,6 +88,8 @@ def lib():
     L.pf_read_image.argtypes = [C.c_char_p, vp, C.c_int, C.c_int]
     L.pf_jpeg_info.argtypes = [C.c_char_p, C.c_size_t, ip, ip, ip]
     L.pf_jpeg_decode_bgr.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int]
+    L.pf_jpeg_decode_device.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int, vp]
+    L.pf_feed_jpeg.argtypes = [vp, C.c_char_p, C.c_size_t, dp]
     L.pf_num_levels.argtypes = [vp]
     L.pf_pyramid_type.argtypes = [vp]
     L.pf_grid.argtypes = [vp, ip, dp]
@@ -232,6 +234,22 @@ def decode_jpeg(data):
     return out
 
 
+def jpeg_info(data):
+    """(rows, cols, components) of a JPEG stream"""
+    L = lib(); b = bytes(data); r = C.c_int(); c = C.c_int(); k = C.c_int()
+    if not L.pf_jpeg_info(b, len(b), C.byref(r), C.byref(c), C.byref(k)):
+        raise ValueError("jpeg_info: %s" % L.pf_last_error().decode())
+    return r.value, c.value, k.value
+
+
+def decode_jpeg_device(data, dev_ptr, rows, cols, stream=None):
+    """The same decode with its back end on the GPU (csrc/jpeg_device.hip): BGR8, rows*cols*3 bytes at the device address `dev_ptr`,
+    complete in the order of `stream` (a hipStream_t handle; None = the default stream).  Returns once the work is queued."""
+    L = lib(); b = bytes(data)
+    if not L.pf_jpeg_decode_device(b, len(b), dev_ptr, rows, cols, stream):
+        raise ValueError("decode_jpeg_device: %s" % L.pf_last_error().decode())
+
+
 def tile_owner(opt, ix, iy):
     return lib().pf_tile_owner(C.byref(opt), ix, iy)
 
@@ -279,7 +297,10 @@ class Map2D:
         return bool(lib().pf_prepare(self._h, ppl, pc, ps.shape[0], imgs, ps.ctypes.data_as(C.POINTER(C.c_double))))
 
     def feed(self, img, pose):
-        """img: HxWx3 (BGR) or HxWx4 (BGRA) uint8 numpy array (host), or None for a geometry-only frame."""
+        """img: HxWx3 (BGR) or HxWx4 (BGRA) uint8 numpy array (host), None for a geometry-only frame, or the bytes of a .jpg
+        file (decoded by the map: feed_jpeg)."""
+        if isinstance(img, (bytes, bytearray, memoryview)):
+            return self.feed_jpeg(img, pose)
         p, pp = _pose(pose)
         if img is None:
             return bool(lib().pf_feed(self._h, None, pp))
@@ -300,6 +321,13 @@ class Map2D:
         p, pp = _pose(pose)
         im = Image(rows, cols, PF_8UC3, data_ptr, step)
         return bool(lib().pf_feed_device(self._h, C.byref(im), pp))
+
+    def feed_jpeg(self, data, pose):
+        """feed(cv::imread(file), pose) in one call: the JPEG stream is decoded into HBM on the map's stream (Huffman on this thread,
+        IDCT / upsampling / colour on the GPU) and rendered from there."""
+        p, pp = _pose(pose)
+        b = bytes(data)
+        return bool(lib().pf_feed_jpeg(self._h, b, len(b), pp))
 
     def read_last_frame(self):
         """test hook: bytes of the most recently uploaded host frame as they lie in HBM"""

@@ -1,15 +1,27 @@
 // c_api.cpp -- extern "C" surface of libpifusion.so (include/pifusion.h).
 #include "dist.hpp"
-#include "jpeg_decode.hpp"
+#include "jpeg_device.hpp"
 #include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 using pf::FusionMap;
 
-struct pf_map { FusionMap impl; pf_map(int t, bool th, const pf_options& o) : impl(t, th, o) {} };
+struct pf_map {
+    FusionMap impl;
+    bool threaded;
+    // pf_feed_jpeg: the decoder's device back end and the keyframes it writes (a ring: a frame is read by the launch its feed queues, on
+    // the stream the decoder's kernels are queued on, so one buffer would do; three keep that from depending on the engine's internals)
+    pf::JpegDevice jpeg;
+    void* jpeg_frame[3] = { nullptr, nullptr, nullptr }; size_t jpeg_frame_cap = 0; unsigned jpeg_next = 0;
+    pf_map(int t, bool th, const pf_options& o) : impl(t, th, o), threaded(th) {}
+    ~pf_map();
+};
+
+pf_map::~pf_map() { if (impl.ok() && impl.use_device()) impl.sync(); pf::jpeg_frames_resize(jpeg_frame, 3, 0); }
 
 extern "C" {
 
@@ -95,6 +107,35 @@ int pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols)
 int pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components) { return pf::jpeg_info(data, len, rows, cols, components); }
 int pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols)
 { return rows > 0 && cols > 0 && pf::jpeg_decode_bgr(data, len, bgr, rows, cols, (size_t)cols * 3); }
+int pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream)
+{
+    static std::mutex mu; static pf::JpegDevice* dec = new pf::JpegDevice();     // process-wide, never torn down (the runtime may be gone at exit)
+    std::lock_guard<std::mutex> l(mu);
+    return rows > 0 && cols > 0 && dec->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
+}
+int pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7])
+{
+    if (!m || !data || !pose) return 0;
+    int rows = 0, cols = 0, comps = 0;
+    if (!pf::jpeg_info(data, len, &rows, &cols, &comps)) return 0;
+    if (m->threaded) {                                    // Map2D::feed on a threaded map takes host pixels (the queue owns a copy)
+        std::vector<uint8_t> px((size_t)rows * cols * 3);
+        if (!pf::jpeg_decode_bgr(data, len, px.data(), rows, cols, (size_t)cols * 3)) return 0;
+        pf_image img = { rows, cols, PF_8UC3, px.data(), 0 };
+        return m->impl.feed(&img, pose, false);
+    }
+    if (!m->impl.ok() || !m->impl.use_device()) { pf::set_error("pf_feed_jpeg: no device"); return 0; }
+    const size_t bytes = (size_t)rows * cols * 3;
+    if (m->jpeg_frame_cap < bytes) {
+        if (!m->impl.sync()) return 0;
+        if (!pf::jpeg_frames_resize(m->jpeg_frame, 3, bytes)) return 0;
+        m->jpeg_frame_cap = bytes;
+    }
+    void* frame = m->jpeg_frame[m->jpeg_next++ % 3];
+    if (!m->jpeg.decode_to(data, len, (uint8_t*)frame, rows, cols, (void*)m->impl.stream())) return 0;
+    pf_image img = { rows, cols, PF_8UC3, frame, 0 };
+    return m->impl.feed(&img, pose, true);
+}
 int pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return m && rows && cols && tx0 && ty0 && m->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }
 

@@ -55,8 +55,20 @@ struct Bits {
     const uint8_t* p; const uint8_t* end;
     uint64_t acc = 0; int n = 0, fake = 0, marker = 0; bool starved = false;
     Bits(const uint8_t* b, const uint8_t* e) : p(b), end(e) {}
-    void fill()
+    __attribute__((always_inline)) void fill()
     {
+        if (!marker && end - p >= 8) {                    // eight bytes without a 0xFF among them: take as many as fit at once
+            uint64_t v;
+            std::memcpy(&v, p, 8);
+            v = __builtin_bswap64(v);
+            const uint64_t inv = ~v;
+            if (!((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull)) {
+                const int take = (64 - n) >> 3, rest = (64 - n) & 7;
+                if (n < 64) acc |= (v >> n) & ~((1ull << rest) - 1);
+                p += take; n += take * 8;
+                return;
+            }
+        }
         while (n <= 56) {
             int b = 0;
             if (!marker && p < end) {
@@ -75,11 +87,11 @@ struct Bits {
             n += 8;
         }
     }
-    inline int peek(int k) { if (n < k) fill(); return (int)(acc >> (64 - k)); }
-    inline void drop(int k) { acc <<= k; n -= k; if (n < fake) { starved = true; fake = n; } }
-    inline int get(int k) { if (!k) return 0; const int v = peek(k); drop(k); return v; }
-    inline int bit() { return get(1); }
-    inline int symbol(const Huff& h)
+    __attribute__((always_inline)) int peek(int k) { if (n < k) fill(); return (int)(acc >> (64 - k)); }
+    __attribute__((always_inline)) void drop(int k) { acc <<= k; n -= k; if (n < fake) { starved = true; fake = n; } }
+    __attribute__((always_inline)) int get(int k) { if (!k) return 0; const int v = peek(k); drop(k); return v; }
+    __attribute__((always_inline)) int bit() { return get(1); }
+    __attribute__((always_inline)) int symbol(const Huff& h)
     {
         const int pre = peek(16);
         const uint16_t e = h.look[pre >> 7];
@@ -108,7 +120,8 @@ struct Comp {
     int bw = 0, bh = 0;                  // blocks held (whole MCUs)
     int w = 0, ht = 0;                   // downsampled_width / _height: the samples that are real
     int td = 0, ta = 0, pred = 0;
-    std::vector<int16_t> coef;
+    int16_t* coef = nullptr;             // bw*bh blocks of 64, natural order
+    std::vector<int16_t> own;            // ... held here unless the caller brought the storage
     std::vector<uint8_t> plane;          // bw*8 x bh*8 after the IDCT
 };
 
@@ -180,8 +193,15 @@ struct Decoder {
     uint16_t qt[4][64]; bool qt_set[4] = { false, false, false, false };
     Huff dc[4], ac[4];
     std::string err;
+    int16_t* store = nullptr; size_t store_cap = 0;      // optional caller storage for the coefficients of all components
 
     Decoder(const uint8_t* data, size_t len) : d(data), n(len) {}
+    size_t coef_count() const
+    {
+        size_t t = 0;
+        for (int c = 0; c < ncomp; c++) t += (size_t)comp[c].bw * comp[c].bh * 64;
+        return t;
+    }
     bool fail(const char* m) { err = std::string("jpeg: ") + m; return false; }
     int u16(size_t at) const { return (d[at] << 8) | d[at + 1]; }
 
@@ -230,13 +250,21 @@ struct Decoder {
                 for (int c = 0; c < ncomp; c++)
                     if (hmax % comp[c].h || vmax % comp[c].v) return fail("fractional sampling ratios are not supported");
                 have_frame = true;
-                if (stop_at_frame) return true;
                 mcux = (W + 8 * hmax - 1) / (8 * hmax); mcuy = (H + 8 * vmax - 1) / (8 * vmax);
                 for (int c = 0; c < ncomp; c++) {
                     Comp& k = comp[c];
                     k.bw = mcux * k.h; k.bh = mcuy * k.v;
                     k.w = (W * k.h + hmax - 1) / hmax; k.ht = (H * k.v + vmax - 1) / vmax;
-                    k.coef.assign((size_t)k.bw * k.bh * 64, 0);
+                }
+                if (stop_at_frame) return true;
+                if (store && store_cap < coef_count()) return fail("coefficient storage too small");
+                size_t off = 0;
+                for (int c = 0; c < ncomp; c++) {
+                    Comp& k = comp[c];
+                    const size_t cnt = (size_t)k.bw * k.bh * 64;
+                    if (store) { k.coef = store + off; std::memset(k.coef, 0, cnt * sizeof(int16_t)); }
+                    else { k.own.assign(cnt, 0); k.coef = k.own.data(); }
+                    off += cnt;
                 }
             } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
                 return fail("unsupported coding process (lossless, hierarchical or arithmetic)");
@@ -337,8 +365,10 @@ struct Decoder {
     }
 
     // jdhuff.c decode_mcu_slow
-    void block_sequential(Bits& br, Comp& k, int16_t* blk)
+    // (the block decoders work on a copy of the reader: with every method inlined its fields live in registers)
+    void block_sequential(Bits& io, Comp& k, int16_t* blk)
     {
+        Bits br = io;
         int s = br.symbol(dc[k.td]);
         if (s) { const int r = br.get(s); s = extend(r, s); }
         k.pred += s;
@@ -350,19 +380,23 @@ struct Decoder {
             if (s) { i += r; const int x = br.get(s); blk[kZigzag[i]] = (int16_t)extend(x, s); }
             else { if (r != 15) break; i += 15; }
         }
+        io = br;
     }
     // jdphuff.c decode_mcu_DC_first
-    void block_dc_first(Bits& br, Comp& k, int16_t* blk, int Al)
+    void block_dc_first(Bits& io, Comp& k, int16_t* blk, int Al)
     {
+        Bits br = io;
         int s = br.symbol(dc[k.td]);
         if (s) { const int r = br.get(s); s = extend(r, s); }
         k.pred += s;
         blk[0] = (int16_t)((unsigned)k.pred << Al);
+        io = br;
     }
     // jdphuff.c decode_mcu_AC_first
-    void block_ac_first(Bits& br, Comp& k, int16_t* blk, int Ss, int Se, int Al, int& eobrun)
+    void block_ac_first(Bits& io, Comp& k, int16_t* blk, int Ss, int Se, int Al, int& eobrun)
     {
         if (eobrun > 0) { eobrun--; return; }
+        Bits br = io;
         const Huff& a = ac[k.ta];
         for (int i = Ss; i <= Se; i++) {
             int s = br.symbol(a);
@@ -371,10 +405,12 @@ struct Decoder {
             else if (r == 15) i += 15;
             else { eobrun = 1 << r; if (r) eobrun += br.get(r); eobrun--; break; }
         }
+        io = br;
     }
     // jdphuff.c decode_mcu_AC_refine
-    void block_ac_refine(Bits& br, Comp& k, int16_t* blk, int Ss, int Se, int Al, int& eobrun)
+    void block_ac_refine(Bits& io, Comp& k, int16_t* blk, int Ss, int Se, int Al, int& eobrun)
     {
+        Bits br = io;
         const int p1 = 1 << Al, m1 = -(1 << Al);
         const Huff& a = ac[k.ta];
         int i = Ss;
@@ -400,6 +436,7 @@ struct Decoder {
             for (; i <= Se; i++) { int16_t* c = blk + kZigzag[i]; if (*c) refine(c); }
             eobrun--;
         }
+        io = br;
     }
 
     bool reconstruct()
@@ -412,7 +449,7 @@ struct Decoder {
             for (int by = 0; by < k.bh; by++)
                 for (int bx = 0; bx < k.bw; bx++)
                     idct_islow(&k.coef[((size_t)by * k.bw + bx) * 64], qt[k.tq], &k.plane[(size_t)by * 8 * stride + bx * 8], stride);
-            std::vector<int16_t>().swap(k.coef);
+            std::vector<int16_t>().swap(k.own); k.coef = nullptr;
         }
         return true;
     }
@@ -462,6 +499,15 @@ struct Decoder {
         for (int x = 0; x < w; x++) for (int r = 0; r < he; r++) out[x * he + r] = in[x];
     }
 
+    // jdapimin.c default_decompress_parms: what the three components are
+    bool is_ycc() const
+    {
+        if (ncomp != 3) return false;
+        if (jfif) return true;
+        if (adobe) return adobe_transform != 0;
+        return !(comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B');
+    }
+
     bool output_bgr(uint8_t* out, size_t stride)
     {
         // jdcolor.c build_ycc_rgb_table, SCALEBITS 16
@@ -474,12 +520,7 @@ struct Decoder {
             }
             tab = true;
         }
-        bool ycc = true;
-        if (ncomp == 3) {
-            if (jfif) ycc = true;
-            else if (adobe) ycc = adobe_transform != 0;
-            else ycc = !(comp[0].id == 'R' && comp[1].id == 'G' && comp[2].id == 'B');
-        }
+        const bool ycc = is_ycc();
         const size_t lw = (size_t)mcux * hmax * 8 + 8;
         std::vector<uint8_t> l0(lw), l1(lw), l2(lw);
         auto clamp = [](int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); };
@@ -523,6 +564,40 @@ bool jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, in
     if (!dec.read_headers(false) || !dec.reconstruct()) { set_error(dec.err); return false; }
     if (rows != dec.H || cols != dec.W || stride < (size_t)cols * 3) { set_error("jpeg: the output buffer does not have the image's size"); return false; }
     return dec.output_bgr(bgr, stride);
+}
+
+static void describe(const Decoder& dec, JpegFrame& f)
+{
+    f.rows = dec.H; f.cols = dec.W; f.ncomp = dec.ncomp; f.hmax = dec.hmax; f.vmax = dec.vmax; f.mcux = dec.mcux; f.mcuy = dec.mcuy;
+    f.ycc = dec.is_ycc(); f.coef_count = dec.coef_count();
+    size_t off = 0;
+    for (int c = 0; c < dec.ncomp; c++) {
+        const Comp& k = dec.comp[c];
+        JpegComponent& o = f.c[c];
+        o.h = k.h; o.v = k.v; o.bw = k.bw; o.bh = k.bh; o.w = k.w; o.ht = k.ht; o.coef_off = off;
+        std::memcpy(o.q, dec.qt[k.tq], sizeof(o.q));
+        off += (size_t)k.bw * k.bh * 64;
+    }
+}
+
+bool jpeg_frame_info(const uint8_t* data, size_t len, JpegFrame& f)
+{
+    Decoder dec(data, len);
+    if (!data || !dec.read_headers(true)) { set_error(data ? dec.err : "jpeg: null buffer"); return false; }
+    describe(dec, f);
+    return true;
+}
+
+bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t* store, size_t store_cap)
+{
+    Decoder dec(data, len);
+    dec.store = store; dec.store_cap = store_cap;
+    if (!data || !store) { set_error("jpeg: null buffer"); return false; }
+    if (!dec.read_headers(false)) { set_error(dec.err); return false; }
+    for (int c = 0; c < dec.ncomp; c++)
+        if (!dec.qt_set[dec.comp[c].tq]) { set_error("jpeg: frame uses a quantisation table that was not defined"); return false; }
+    describe(dec, f);
+    return true;
 }
 
 bool read_file_bytes(const char* filename, std::vector<uint8_t>& out)

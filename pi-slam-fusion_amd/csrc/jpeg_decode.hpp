@@ -10,6 +10,25 @@ void set_error(const std::string& msg);          // fusion_map.cpp: what pf_last
 bool jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* comps);
 // 8-bit BGR, rows x cols as jpeg_info reports them, `stride` bytes per row
 bool jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols, size_t stride);
+
+// The entropy stage alone (parse + Huffman, sequential or progressive): what the device back end (jpeg_device.hip) starts from.
+struct JpegComponent {
+    int h, v;                    // sampling factors
+    int bw, bh;                  // blocks held: whole MCUs
+    int w, ht;                   // real samples (libjpeg's downsampled_width / _height)
+    uint16_t q[64];              // quantiser, natural order
+    size_t coef_off;             // first coefficient of the component in the store, in int16 units
+};
+struct JpegFrame {
+    int rows, cols, ncomp, hmax, vmax, mcux, mcuy;
+    bool ycc;                    // the three components are Y, Cb, Cr (else R, G, B)
+    JpegComponent c[3];
+    size_t coef_count;           // int16 values the store must hold
+};
+// geometry only (quantisers are not final before the scans have been read)
+bool jpeg_frame_info(const uint8_t* data, size_t len, JpegFrame& f);
+// coefficients of every block, natural order, 64 per block, blocks row-major per component, components one after another in `store`
+bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t* store, size_t store_cap);
 bool read_file_bytes(const char* filename, std::vector<uint8_t>& out);
 bool read_image_file(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols);
 }  // namespace pf

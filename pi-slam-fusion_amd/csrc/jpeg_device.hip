@@ -1,0 +1,337 @@
+// jpeg_device.hip -- the back end of cv::imread's JPEG leg (backup/map2dfusion.cpp:129-132) on the GPU: the host does the
+// part that is serial (markers + Huffman, jpeg_decode.cpp's entropy stage, a quarter to a third of a host decode), the
+// coefficients cross PCIe once (the size of the frame they become), and two kernels do what libjpeg does after the entropy
+// decoder -- dequantise + ISLOW IDCT per 8x8 block (jidctint.c) into component planes, then fancy upsampling (jdsample.c) and
+// YCbCr -> BGR (jdcolor.c) per pixel -- writing the BGR8 keyframe where the level kernel reads it.  Integer arithmetic
+// throughout: byte-equal to jpeg_decode.cpp and therefore to libjpeg-turbo (tests/test_gpu_jpeg.py).
+// Both kernels are HBM-bound byte work: 2 B of coefficients in and 1 B out per sample; 1.5 B of planes in and 3 B out per pixel
+// (4:2:0).  A 4000 x 3000 4:2:0 frame: 54 MB + 54 MB.
+#include "jpeg_device.hpp"
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstring>
+
+namespace pf {
+
+struct JpegDevComp {
+    int bw, bh, w, ht, he, ve, stride;         // blocks held, real samples, expansion to full resolution, plane row pitch (bw * 8)
+    unsigned coef_off, plane_off;              // int16 / byte offsets of the component
+    int pad_[3];                               // q on a 16-byte boundary: a thread loads a row of it at once
+    uint16_t q[64];
+};
+struct JpegDevFrame {
+    int rows, cols, ncomp, ycc;
+    unsigned block_first[4];                   // first block of each component in the launch's numbering; [ncomp] = all blocks
+    JpegDevComp c[3];
+};
+static_assert(offsetof(JpegDevFrame, c[0].q) % 16 == 0 && sizeof(JpegDevComp) % 16 == 0, "quantiser rows are loaded 16 bytes at a time");
+static_assert(sizeof(JpegDevFrame) <= 1024, "the header travels in the first KiB of the coefficient buffer");
+constexpr size_t kHeaderBytes = 1024;
+
+namespace {
+
+__device__ inline int dsc(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ inline int lim(int x)              // jdmaster.c prepare_range_limit_table, IDCT part, after "& RANGE_MASK"
+{
+    x &= 1023;
+    return x < 128 ? x + 128 : x < 512 ? 255 : x < 896 ? 0 : x - 896;
+}
+
+// jidctint.c: the 8-point pass on values already in registers; `s0` / `sh`: pre-shift of the even DC pair and the final descale
+__device__ inline void idct8(const int v[8], int out[8], int sh)
+{
+    constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+                  F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    int z2 = v[2], z3 = v[6];
+    int z1 = (z2 + z3) * F0_541;
+    int tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+    int tmp0 = (int)((unsigned)(v[0] + v[4]) << 13), tmp1 = (int)((unsigned)(v[0] - v[4]) << 13);
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = v[7]; tmp1 = v[5]; tmp2 = v[3]; tmp3 = v[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = dsc(tmp10 + tmp3, sh); out[7] = dsc(tmp10 - tmp3, sh);
+    out[1] = dsc(tmp11 + tmp2, sh); out[6] = dsc(tmp11 - tmp2, sh);
+    out[2] = dsc(tmp12 + tmp1, sh); out[5] = dsc(tmp12 - tmp1, sh);
+    out[3] = dsc(tmp13 + tmp0, sh); out[4] = dsc(tmp13 - tmp0, sh);
+}
+
+// 256 threads = 32 blocks of 8 x 8: a thread loads one row of its block (16 B) and its quantisers, the block is transposed through
+// LDS (72-word pitch per block: the eight blocks of a wave sit on disjoint banks for the column accesses), a thread runs the column
+// pass in place, then the row pass, and stores 8 bytes of the component plane.
+constexpr int kPitch = 72;
+__global__ __launch_bounds__(256) void k_jpeg_idct(const JpegDevFrame* __restrict__ F, const int16_t* __restrict__ coef, uint8_t* __restrict__ planes)
+{
+    __shared__ int ws[32 * kPitch];
+    const int t = threadIdx.x, lb = t >> 3, j = t & 7;
+    const unsigned blk = blockIdx.x * 32u + (unsigned)lb;
+    const int nc = F->ncomp;
+    const bool live = blk < F->block_first[nc];
+    int c = 0;
+    if (nc > 1 && blk >= F->block_first[1]) c = 1;
+    if (nc > 2 && blk >= F->block_first[2]) c = 2;
+    const JpegDevComp& C = F->c[c];
+    const unsigned b = blk - F->block_first[c];
+    int* w = ws + lb * kPitch;
+    if (live) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(coef + C.coef_off + (size_t)b * 64 + 8 * j);
+        const uint4 qr = *reinterpret_cast<const uint4*>(C.q + 8 * j);
+        const unsigned rv[4] = { raw.x, raw.y, raw.z, raw.w }, qv[4] = { qr.x, qr.y, qr.z, qr.w };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            w[8 * j + 2 * k] = (int)(short)(rv[k] & 0xffff) * (int)(qv[k] & 0xffff);
+            w[8 * j + 2 * k + 1] = (int)(short)(rv[k] >> 16) * (int)(qv[k] >> 16);
+        }
+    }
+    __syncthreads();
+    int v[8], o[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) v[r] = w[8 * r + j];                     // column j
+    idct8(v, o, 11);                                                     // CONST_BITS - PASS1_BITS
+#pragma unroll
+    for (int r = 0; r < 8; r++) w[8 * r + j] = o[r];                     // in place: the thread owns the column
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = w[8 * j + k];                     // row j
+    idct8(v, o, 18);                                                     // CONST_BITS + PASS1_BITS + 3
+    if (live) {
+        const unsigned by = b / (unsigned)C.bw, bx = b - by * (unsigned)C.bw;
+        uint2 px;
+        px.x = (unsigned)lim(o[0]) | ((unsigned)lim(o[1]) << 8) | ((unsigned)lim(o[2]) << 16) | ((unsigned)lim(o[3]) << 24);
+        px.y = (unsigned)lim(o[4]) | ((unsigned)lim(o[5]) << 8) | ((unsigned)lim(o[6]) << 16) | ((unsigned)lim(o[7]) << 24);
+        *reinterpret_cast<uint2*>(planes + C.plane_off + (size_t)(by * 8 + j) * C.stride + bx * 8) = px;
+    }
+}
+
+// jdsample.c: the sample of a component at full-resolution position (x, y).  Rows beyond the real ones repeat the last real row
+// (jdmainct.c's context rows); columns beyond are never asked for.
+__device__ inline int sample_at(const JpegDevComp& C, const uint8_t* __restrict__ planes, int x, int y)
+{
+    const uint8_t* p = planes + C.plane_off;
+    const int he = C.he, ve = C.ve, w = C.w, last = C.ht - 1, st = C.stride;
+    auto row = [&](int r) { r = r < 0 ? 0 : r > last ? last : r; return p + (size_t)r * st; };
+    if (he == 1 && ve == 1) return row(y)[x];
+    if (he == 2 && ve == 1) {
+        const uint8_t* in = row(y);
+        const int cx = x >> 1;
+        if (w <= 2) return in[cx];
+        if (x & 1) return cx == w - 1 ? in[cx] : (in[cx] * 3 + in[cx + 1] + 2) >> 2;
+        return cx == 0 ? in[0] : (in[cx] * 3 + in[cx - 1] + 1) >> 2;
+    }
+    if (he == 1 && ve == 2) {
+        const int cy = y >> 1;
+        return (row(cy)[x] * 3 + row((y & 1) ? cy + 1 : cy - 1)[x] + ((y & 1) ? 2 : 1)) >> 2;
+    }
+    if (he == 2 && ve == 2 && w > 2) {
+        const int cy = y >> 1, cx = x >> 1;
+        const uint8_t* in0 = row(cy); const uint8_t* in1 = row((y & 1) ? cy + 1 : cy - 1);
+        const int cur = in0[cx] * 3 + in1[cx];
+        if (x & 1) return cx == w - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + in0[cx + 1] * 3 + in1[cx + 1] + 7) >> 4;
+        return cx == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + in0[cx - 1] * 3 + in1[cx - 1] + 8) >> 4;
+    }
+    return row(y / ve)[x / he];
+}
+
+__device__ inline unsigned clamp8(int v) { return (unsigned)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// four pixels of a row per thread: upsample, jdcolor.c's YCbCr -> RGB (SCALEBITS 16), BGR out (what cv::imread hands over)
+__global__ __launch_bounds__(256) void k_jpeg_colour(const JpegDevFrame* __restrict__ F, const uint8_t* __restrict__ planes, uint8_t* __restrict__ bgr)
+{
+    const int cols = F->cols, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x0 >= cols) return;
+    const int nc = F->ncomp, ycc = F->ycc;
+    unsigned char o[12];
+    const int n = cols - x0 < 4 ? cols - x0 : 4;
+    for (int i = 0; i < n; i++) {
+        const int x = x0 + i;
+        const int a = sample_at(F->c[0], planes, x, y);
+        int r, g, b;
+        if (nc == 1) r = g = b = a;
+        else {
+            const int u = sample_at(F->c[1], planes, x, y), v = sample_at(F->c[2], planes, x, y);
+            if (ycc) {
+                const int cb = u - 128, cr = v - 128;
+                r = (int)clamp8(a + ((91881 * cr + 32768) >> 16));
+                g = (int)clamp8(a + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+                b = (int)clamp8(a + ((116130 * cb + 32768) >> 16));
+            } else { r = a; g = u; b = v; }
+        }
+        o[3 * i] = (unsigned char)b; o[3 * i + 1] = (unsigned char)g; o[3 * i + 2] = (unsigned char)r;
+    }
+    uint8_t* dst = bgr + ((size_t)y * cols + x0) * 3;
+    if (n == 4 && ((cols * 3) & 3) == 0) {
+        unsigned* d4 = reinterpret_cast<unsigned*>(dst);
+        d4[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((unsigned)o[3] << 24);
+        d4[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((unsigned)o[7] << 24);
+        d4[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((unsigned)o[11] << 24);
+    } else
+        for (int i = 0; i < 3 * n; i++) dst[i] = o[i];
+}
+
+// The shapes cameras write (three components, luma at full resolution, both chroma planes expanded HE x VE in {1x1, 2x1, 2x2} with
+// more than two samples a row, cols a multiple of 8): eight pixels of a row per thread -- the luma bytes in one load, the chroma
+// samples of the row (and of its neighbour row for 2x2) as one word plus the two samples next to it, 24 bytes out in six words.
+// Same arithmetic as sample_at(), case by case.
+template <int HE, int VE>
+__global__ __launch_bounds__(256) void k_jpeg_colour8(const JpegDevFrame* __restrict__ F, const uint8_t* __restrict__ planes, uint8_t* __restrict__ bgr)
+{
+    const int cols = F->cols, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (x0 >= cols) return;
+    const JpegDevComp& Y = F->c[0];
+    const uint2 yy = *reinterpret_cast<const uint2*>(planes + Y.plane_off + (size_t)y * Y.stride + x0);
+    int ch[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const JpegDevComp& C = F->c[1 + k];
+        const uint8_t* p = planes + C.plane_off;
+        const int last = C.ht - 1, w = C.w;
+        if (HE == 1) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p + (size_t)y * C.stride + x0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) ch[k][i] = (int)(((i < 4 ? v.x : v.y) >> (8 * (i & 3))) & 255);
+        } else {
+            const int cy = VE == 2 ? y >> 1 : y, cx0 = x0 >> 1;
+            const int ny = VE == 2 ? ((y & 1) ? (cy + 1 > last ? last : cy + 1) : (cy - 1 < 0 ? 0 : cy - 1)) : cy;
+            const uint8_t* in0 = p + (size_t)cy * C.stride; const uint8_t* in1 = p + (size_t)ny * C.stride;
+            const int xl = cx0 > 0 ? cx0 - 1 : 0, xr = cx0 + 4 < w ? cx0 + 4 : w - 1;
+            const unsigned m0 = *reinterpret_cast<const unsigned*>(in0 + cx0);
+            int cs[6];
+            if (VE == 2) {
+                const unsigned m1 = *reinterpret_cast<const unsigned*>(in1 + cx0);
+                cs[0] = in0[xl] * 3 + in1[xl]; cs[5] = in0[xr] * 3 + in1[xr];
+#pragma unroll
+                for (int i = 0; i < 4; i++) cs[1 + i] = (int)((m0 >> (8 * i)) & 255) * 3 + (int)((m1 >> (8 * i)) & 255);
+            } else {
+                cs[0] = in0[xl]; cs[5] = in0[xr];
+#pragma unroll
+                for (int i = 0; i < 4; i++) cs[1 + i] = (int)((m0 >> (8 * i)) & 255);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int cx = cx0 + (i >> 1), c = cs[1 + (i >> 1)];
+                if (VE == 2) ch[k][i] = (i & 1) ? (cx == w - 1 ? (c * 4 + 7) >> 4 : (c * 3 + cs[2 + (i >> 1)] + 7) >> 4)
+                                               : (cx == 0 ? (c * 4 + 8) >> 4 : (c * 3 + cs[i >> 1] + 8) >> 4);
+                else         ch[k][i] = (i & 1) ? (cx == w - 1 ? c : (c * 3 + cs[2 + (i >> 1)] + 2) >> 2)
+                                               : (cx == 0 ? c : (c * 3 + cs[i >> 1] + 1) >> 2);
+            }
+        }
+    }
+    const int ycc = F->ycc;
+    unsigned o[24];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int a = (int)(((i < 4 ? yy.x : yy.y) >> (8 * (i & 3))) & 255), u = ch[0][i], v = ch[1][i];
+        if (ycc) {
+            const int cb = u - 128, cr = v - 128;
+            o[3 * i + 2] = clamp8(a + ((91881 * cr + 32768) >> 16));
+            o[3 * i + 1] = clamp8(a + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+            o[3 * i] = clamp8(a + ((116130 * cb + 32768) >> 16));
+        } else { o[3 * i + 2] = (unsigned)a; o[3 * i + 1] = (unsigned)u; o[3 * i] = (unsigned)v; }
+    }
+    unsigned* d4 = reinterpret_cast<unsigned*>(bgr + ((size_t)y * cols + x0) * 3);
+#pragma unroll
+    for (int i = 0; i < 6; i++) d4[i] = o[4 * i] | (o[4 * i + 1] << 8) | (o[4 * i + 2] << 16) | (o[4 * i + 3] << 24);
+}
+
+bool hip_ok(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return true;
+    set_error(std::string("jpeg device: ") + what + ": " + hipGetErrorString(e));
+    return false;
+}
+
+}  // namespace
+
+bool jpeg_frames_resize(void** bufs, int n, size_t bytes)
+{
+    for (int i = 0; i < n; i++) { if (bufs[i]) (void)hipFree(bufs[i]); bufs[i] = nullptr; }
+    for (int i = 0; bytes && i < n; i++)
+        if (!hip_ok(hipMalloc(&bufs[i], bytes), "keyframe buffer")) return false;
+    return true;
+}
+
+JpegDevice::~JpegDevice()
+{
+    for (auto& s : slot_) {
+        if (s.done) { (void)hipEventSynchronize((hipEvent_t)s.done); (void)hipEventDestroy((hipEvent_t)s.done); }
+        if (s.host) (void)hipHostFree(s.host);
+    }
+    if (dev_) (void)hipFree(dev_);
+    if (planes_) (void)hipFree(planes_);
+}
+
+bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    JpegFrame f;
+    if (!data || !dev_bgr) { set_error("jpeg device: null buffer"); return false; }
+    if (!jpeg_frame_info(data, len, f)) return false;
+    if (f.rows != rows || f.cols != cols) { set_error("jpeg device: the output buffer does not have the image's size"); return false; }
+    const size_t need = kHeaderBytes + f.coef_count * sizeof(int16_t);
+    Slot& s = slot_[next_]; next_ ^= 1;
+    if (s.done && s.used && !hip_ok(hipEventSynchronize((hipEvent_t)s.done), "wait for the staging buffer")) return false;
+    if (s.cap < need) {
+        if (s.host) (void)hipHostFree(s.host);
+        s.host = nullptr; s.cap = 0;
+        if (!hip_ok(hipHostMalloc(&s.host, need, hipHostMallocDefault), "pinned staging buffer")) return false;
+        s.cap = need;
+    }
+    if (!s.done) { hipEvent_t e; if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event")) return false; s.done = e; }
+    if (!jpeg_entropy_decode(data, len, f, (int16_t*)((char*)s.host + kHeaderBytes), f.coef_count)) return false;
+
+    JpegDevFrame h;
+    std::memset(&h, 0, sizeof(h));
+    h.rows = f.rows; h.cols = f.cols; h.ncomp = f.ncomp; h.ycc = f.ycc ? 1 : 0;
+    size_t plane_bytes = 0; unsigned blocks = 0;
+    for (int c = 0; c < f.ncomp; c++) {
+        const JpegComponent& k = f.c[c];
+        JpegDevComp& o = h.c[c];
+        o.bw = k.bw; o.bh = k.bh; o.w = k.w; o.ht = k.ht; o.he = f.hmax / k.h; o.ve = f.vmax / k.v; o.stride = k.bw * 8;
+        o.coef_off = (unsigned)k.coef_off; o.plane_off = (unsigned)plane_bytes;
+        std::memcpy(o.q, k.q, sizeof(o.q));
+        h.block_first[c] = blocks;
+        blocks += (unsigned)(k.bw * k.bh);
+        plane_bytes += (size_t)k.bw * 8 * k.bh * 8;
+    }
+    for (int c = f.ncomp; c < 4; c++) h.block_first[c] = blocks;
+    if (f.coef_count >= (1ull << 31) || plane_bytes >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
+    std::memcpy(s.host, &h, sizeof(h));
+
+    if (dev_cap_ < need) {
+        if (dev_) (void)hipFree(dev_);
+        dev_ = nullptr; dev_cap_ = 0;
+        if (!hip_ok(hipMalloc(&dev_, need), "coefficient buffer")) return false;
+        dev_cap_ = need;
+    }
+    if (planes_cap_ < plane_bytes) {
+        if (planes_) (void)hipFree(planes_);
+        planes_ = nullptr; planes_cap_ = 0;
+        if (!hip_ok(hipMalloc(&planes_, plane_bytes), "plane buffer")) return false;
+        planes_cap_ = plane_bytes;
+    }
+    if (!hip_ok(hipMemcpyAsync(dev_, s.host, need, hipMemcpyHostToDevice, st), "coefficient upload")) return false;
+    if (!hip_ok(hipEventRecord((hipEvent_t)s.done, st), "event record")) return false;
+    s.used = true;
+    const JpegDevFrame* dh = (const JpegDevFrame*)dev_;
+    const int16_t* dcoef = (const int16_t*)((char*)dev_ + kHeaderBytes);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((blocks + 31) / 32), dim3(256), 0, st, dh, dcoef, (uint8_t*)planes_);
+    // the eight-pixel form for the shapes cameras write, the general one otherwise
+    const JpegDevComp* hc = h.c;
+    const bool camera = f.ncomp == 3 && (cols & 7) == 0 && hc[0].he == 1 && hc[0].ve == 1 && hc[1].he == hc[2].he && hc[1].ve == hc[2].ve &&
+                        ((hc[1].he == 1 && hc[1].ve == 1) || (hc[1].he == 2 && hc[1].ve <= 2 && hc[1].w > 2));
+    const dim3 g8((unsigned)((cols + 2047) / 2048), (unsigned)rows);
+    if (camera && hc[1].he == 1) hipLaunchKernelGGL((k_jpeg_colour8<1, 1>), g8, dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
+    else if (camera && hc[1].ve == 1) hipLaunchKernelGGL((k_jpeg_colour8<2, 1>), g8, dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
+    else if (camera) hipLaunchKernelGGL((k_jpeg_colour8<2, 2>), g8, dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
+    else hipLaunchKernelGGL(k_jpeg_colour, dim3((unsigned)((cols + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
+    last_ = { f.coef_count * sizeof(int16_t), plane_bytes, (size_t)rows * cols * 3 };
+    return hip_ok(hipGetLastError(), "kernel launch");
+}
+
+}  // namespace pf

@@ -1,0 +1,31 @@
+// jpeg_device.hpp -- device back end of the file driver's JPEG decode (jpeg_device.hip)
+#pragma once
+#include "jpeg_decode.hpp"
+
+namespace pf {
+
+// One per consumer (a map, or the process-wide one behind pf_jpeg_decode_device).  decode_to() entropy-decodes on the calling thread
+// into a pinned buffer (two, so the next frame's Huffman pass overlaps this frame's copy) and queues the upload and the two kernels on
+// `stream` (a hipStream_t); the BGR8 frame, rows * cols * 3 bytes packed, is complete in `dev_bgr` in stream order.  Not thread-safe.
+class JpegDevice {
+public:
+    struct Bytes { size_t coefficients, planes, frame; };
+    JpegDevice() {}
+    ~JpegDevice();
+    JpegDevice(const JpegDevice&) = delete;
+    JpegDevice& operator=(const JpegDevice&) = delete;
+    bool decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream);
+    Bytes last_bytes() const { return last_; }          // of the most recent frame: what the two kernels read and wrote
+private:
+    struct Slot { void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false; };
+    Slot   slot_[2];
+    int    next_ = 0;
+    void*  dev_ = nullptr;    size_t dev_cap_ = 0;
+    void*  planes_ = nullptr; size_t planes_cap_ = 0;
+    Bytes  last_ = { 0, 0, 0 };
+};
+
+// (re)allocates `n` device buffers of `bytes` each (0: frees them)
+bool jpeg_frames_resize(void** bufs, int n, size_t bytes);
+
+}  // namespace pf

@@ -52,10 +52,13 @@ class DroneMapDataset:
     def __len__(self):
         return len(self.frames)
 
-    def load(self, k):
-        """(BGR uint8 image, pose7) of keyframe k."""
+    def load(self, k, encoded=False):
+        """(BGR uint8 image, pose7) of keyframe k.  encoded=True: a .jpg frame comes back as the file's bytes, for Map2D.feed to decode
+        on the GPU (pf_feed_jpeg)."""
         name, pose = self.frames[k]
         base = os.path.join(self.path, "rgb", name)
+        if encoded and os.path.exists(base + ".jpg"):
+            return open(base + ".jpg", "rb").read(), pose
         for ext in (".jpg", ".png", ".ppm", ".npy"):
             if os.path.exists(base + ext):
                 if ext == ".npy":

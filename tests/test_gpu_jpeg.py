@@ -1,0 +1,97 @@
+"""The JPEG decoder's device back end (csrc/jpeg_device.hip: dequantise + ISLOW IDCT, fancy upsampling, YCbCr -> BGR on the GPU after
+the host's Huffman pass) against the host decoder (csrc/jpeg_decode.cpp) and against libjpeg-turbo's pixels: byte-equal.  Then
+pf_feed_jpeg -- feed(cv::imread(imgfile), pose), backup/map2dfusion.cpp:129-135 -- against the oracle fed libjpeg-turbo's pixels."""
+import io
+
+import numpy as np
+import pytest
+
+import jpeg_enc
+from helpers import jitter_poses, workloads
+from test_jpeg import picture, vectors
+
+pytestmark = pytest.mark.gpu
+
+
+def on_device(pf, stream_bytes):
+    import torch
+    r, c, _ = pf.jpeg_info(stream_bytes)
+    out = torch.full((r, c, 3), 77, dtype=torch.uint8, device="cuda")
+    pf.decode_jpeg_device(stream_bytes, out.data_ptr(), r, c)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def test_device_decode_equals_golden_vectors(pf):
+    for case, stream, rgb in vectors():
+        got = on_device(pf, stream)
+        assert got.shape == rgb.shape and np.array_equal(got[:, :, ::-1], rgb), case
+
+
+def test_device_decode_equals_host_decode_on_other_shapes(pf):
+    Image = pytest.importorskip("PIL.Image")
+    n = 0
+    for (h, w) in [(1, 1), (3, 5), (17, 33), (67, 130), (200, 3), (4, 100), (481, 643), (1080, 1920), (45, 64), (2, 8), (1, 16), (7, 24)]:
+        a = picture(h, w, 3 * h + w)
+        for sub in (0, 1, 2):
+            for opts in ({"quality": 30}, {"quality": 90, "progressive": True}, {"quality": 100, "restart_marker_blocks": 5}):
+                b = io.BytesIO()
+                Image.fromarray(a).save(b, "JPEG", subsampling=sub, **opts)
+                s = b.getvalue()
+                host = pf.decode_jpeg(s)
+                assert np.array_equal(on_device(pf, s), host), (h, w, sub, opts)
+                assert np.array_equal(host[:, :, ::-1], np.asarray(Image.open(io.BytesIO(s)).convert("RGB")))
+                n += 1
+        b = io.BytesIO()
+        Image.fromarray(a).convert("L").save(b, "JPEG", quality=80)
+        assert np.array_equal(on_device(pf, b.getvalue()), pf.decode_jpeg(b.getvalue()))
+    for samp in [((1, 2), (1, 1), (1, 1)), ((4, 1), (1, 1), (1, 1)), ((2, 2), (2, 1), (1, 2)), ((1, 1), (2, 2), (1, 1)), ((1, 4), (1, 1), (1, 1)), ((4, 2), (1, 1), (1, 1))]:
+        for (h, w) in [(9, 7), (33, 47), (40, 3), (3, 40), (130, 250)]:
+            for kw in ({}, {"colour": "rgb"}, {"interleaved": False, "restart": 3, "long_codes": True}):
+                s = jpeg_enc.encode(picture(h, w, h + w), samp, **kw)
+                assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s)), (samp, h, w, kw)
+    assert n == 12 * 3 * 3
+
+
+def test_device_decode_failures_are_reported(pf):
+    import torch
+    _, stream, rgb = vectors()[0]
+    out = torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError, match="size"):
+        pf.decode_jpeg_device(stream, out.data_ptr(), 4, 4)
+    with pytest.raises(ValueError, match="SOI"):
+        pf.decode_jpeg_device(b"not a jpeg", out.data_ptr(), 4, 4)
+
+
+@pytest.mark.parametrize("thread,ff", [(False, 0), (False, 1), (True, 0)])
+def test_feed_jpeg_equals_oracle_fed_the_reference_decoders_pixels(pf, orc, thread, ff):
+    Image = pytest.importorskip("PIL.Image")
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(9, seed=5)
+    streams, frames = [], []
+    for k in range(len(poses)):
+        y, x = np.mgrid[0:480, 0:640]
+        a = np.stack([(x * 3 + 40 * k) % 256, (y * 2 + x) % 256, ((x // 16 + y // 16) % 2) * 200 + 20], -1).astype(np.int32)
+        a = (a + wl.noise_frame(480, 640, 300 + k) // 8).clip(0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(a).save(b, "JPEG", quality=85, subsampling=[2, 1, 0][k % 3], progressive=bool(k & 1))
+        streams.append(b.getvalue())
+        frames.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))[:, :, ::-1]))
+    o = orc.OracleMap(force_float=ff)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:3])
+    for k in range(len(poses)):
+        assert o.feed(frames[k], poses[k])
+    ref = o.save()[0]
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, thread, force_float=ff)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:3])
+    for k in range(len(poses)):
+        assert m.feed_jpeg(streams[k], poses[k])
+    m.sync()
+    got = m.save_to_memory()[0]
+    # a stream of the wrong size is rejected as feed() rejects such a frame; a broken one is an error
+    small = io.BytesIO(); Image.fromarray(frames[0][:100, :100]).save(small, "JPEG")
+    assert not m.feed_jpeg(small.getvalue(), poses[0]) or thread
+    assert not m.feed_jpeg(b"\xff\xd8\xff", poses[0])
+    m.close()
+    assert np.array_equal(got, ref)

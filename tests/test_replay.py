@@ -91,7 +91,8 @@ def test_dataset_replay_equals_oracle(pf, orc, tmp_path, thread, ff):
 
 
 @pytest.mark.gpu
-def test_jpeg_dataset_replay_equals_oracle(pf, orc, tmp_path):
+@pytest.mark.parametrize("thread,extra_arg", [(0, None), (1, None), (0, "Map2D.DecodeOnHost=1")])
+def test_jpeg_dataset_replay_equals_oracle(pf, orc, tmp_path, thread, extra_arg):
     """The dataset as the reference ships it: rgb/<name>.jpg.  Both file drivers decode the frames with the library
     (cv::imread's place, backup/map2dfusion.cpp:129-132); the oracle is fed what libjpeg-turbo (Pillow) decodes."""
     import io
@@ -111,17 +112,18 @@ def test_jpeg_dataset_replay_equals_oracle(pf, orc, tmp_path):
         Image.fromarray(a).save(b, "JPEG", quality=88, subsampling=[2, 1, 0][k % 3], progressive=bool(k & 1))
         open(os.path.join(d, "rgb", "%06d.jpg" % k), "wb").write(b.getvalue())
         frames.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))[:, :, ::-1]))
-    ref = oracle_of(orc, cam, poses, frames, plane, 3, 3, 0)
+    ref = oracle_of(orc, cam, poses, frames, plane, 3, 0 if thread else 3, 0)
 
     exe = build_replay(str(tmp_path))
     out = str(tmp_path / "cpp.png")
-    r = subprocess.run([exe, d, "Map2D.Thread=0", "Map.File2Save=" + out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    r = subprocess.run([exe, d, "Map2D.Thread=%d" % thread, "Map.File2Save=" + out] + ([extra_arg] if extra_arg else []),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     assert b"Loaded 3 frames" in r.stdout and b"Fed 5 frames" in r.stdout
     assert np.array_equal(np.asarray(Image.open(out).convert("RGB"))[:, :, ::-1], ref)
 
     out2 = str(tmp_path / "py.png")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay.py"), d, "--prepare", "3", "--thread", "0", "--out", out2],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "replay.py"), d, "--prepare", "3", "--thread", str(thread), "--out", out2],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()
     assert np.array_equal(np.asarray(Image.open(out2).convert("RGB"))[:, :, ::-1], ref)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Rates of the file driver's JPEG leg on this box (one host thread): a 4000 x 3000 keyframe as a camera writes it (4:2:0, quality 90).
+  host decode (csrc/jpeg_decode.cpp), libjpeg-turbo through Pillow (SIMD), and the split decode -- Huffman on the host, IDCT / upsampling /
+  colour on the GPU (csrc/jpeg_device.hip) -- alone and as pf_feed_jpeg into a map (decode + render of the keyframe).
+usage: python tools/jpeg_rate.py [--frames 12] [--md out.md]        (kernel times: run under rocprofv3 --kernel-trace --stats)"""
+import argparse, io, os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import bench
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=12); ap.add_argument("--md", default=None)
+ap.add_argument("--decode-only", action="store_true", help="only N split decodes of the 4:2:0 q90 frame (the run to put under rocprofv3)")
+a = ap.parse_args()
+pf = bench.load_package()
+import importlib
+wl = importlib.import_module("pi_slam_fusion_amd.workloads")
+from PIL import Image
+
+cam = bench.CAM
+h, w = cam[1], cam[0]
+rng = np.random.default_rng(0)
+y, x = np.mgrid[0:h, 0:w]
+pic = ((np.sin(x / 37.0) * 60 + np.cos(y / 23.0) * 60 + 128)[..., None] + rng.normal(0, 12, (h, w, 3))).clip(0, 255).astype(np.uint8)
+if a.decode_only:
+    b = io.BytesIO(); Image.fromarray(pic).save(b, "JPEG", quality=90, subsampling=2); s = b.getvalue()
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(a.frames):
+        pf.decode_jpeg_device(s, out.data_ptr(), h, w)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), pf.decode_jpeg(s))
+    print("decoded %d frames" % a.frames)
+    sys.exit(0)
+rows = []
+for name, kw in [("4:2:0 q90", dict(quality=90, subsampling=2)), ("4:2:0 q75", dict(quality=75, subsampling=2)), ("4:4:4 q90", dict(quality=90, subsampling=0)),
+                 ("4:2:0 q90 progressive", dict(quality=90, subsampling=2, progressive=True))]:
+    b = io.BytesIO(); Image.fromarray(pic).save(b, "JPEG", **kw); s = b.getvalue()
+    n = a.frames
+    t = time.perf_counter(); ref = None
+    for _ in range(3):
+        ref = pf.decode_jpeg(s)
+    t_host = (time.perf_counter() - t) / 3
+    t = time.perf_counter()
+    for _ in range(3):
+        pil = np.asarray(Image.open(io.BytesIO(s)).convert("RGB"))
+    t_pil = (time.perf_counter() - t) / 3
+    assert np.array_equal(ref[:, :, ::-1], pil)
+    out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+    pf.decode_jpeg_device(s, out.data_ptr(), h, w); torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), ref)
+    t = time.perf_counter()
+    for _ in range(n):
+        pf.decode_jpeg_device(s, out.data_ptr(), h, w)
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t) / n
+    # the GPU part alone: events around the queued work of one frame (upload + two kernels)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record(); pf.decode_jpeg_device(s, out.data_ptr(), h, w); e1.record(); torch.cuda.synchronize()
+    # (the default stream carries both; the event pair brackets host time too, so this is an upper bound of the GPU part)
+    rows.append((name, len(s) / 1e6, t_host, t_pil, t_dev))
+    print("%-24s %.2f MB: host decode %.1f ms, Pillow %.1f ms, split decode %.1f ms per frame" % (name, len(s) / 1e6, t_host * 1e3, t_pil * 1e3, t_dev * 1e3), flush=True)
+
+# into a map: keyframes of the bench sortie as JPEG streams
+poses = wl.serpentine(cam, 100.0, a.frames + 4)
+b = io.BytesIO(); Image.fromarray(pic).save(b, "JPEG", quality=90, subsampling=2); s = b.getvalue()
+res = {}
+for mode in ("feed_jpeg", "decode_then_feed"):
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1)
+    assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:4])
+    for k in range(2):
+        m.feed_jpeg(s, poses[k]) if mode == "feed_jpeg" else m.feed(pf.decode_jpeg(s), poses[k])
+    m.sync()
+    t = time.perf_counter()
+    for k in range(2, 2 + a.frames):
+        m.feed_jpeg(s, poses[k]) if mode == "feed_jpeg" else m.feed(pf.decode_jpeg(s), poses[k])
+    m.sync()
+    res[mode] = a.frames / (time.perf_counter() - t)
+    res[mode + "_img"] = m.save_to_memory()[0]
+    m.close()
+assert np.array_equal(res["feed_jpeg_img"], res["decode_then_feed_img"])
+print("into a map: pf_feed_jpeg %.1f keyframes/s, host decode + pf_feed %.1f keyframes/s (one host thread; same mosaic)" % (res["feed_jpeg"], res["decode_then_feed"]), flush=True)
+if a.md:
+    with open(a.md, "w") as f:
+        f.write("| stream (4000 x 3000) | size | host decode (`jpeg_decode.cpp`) | libjpeg-turbo via Pillow (SIMD) | split decode: Huffman on the host, the rest on the GPU (`jpeg_device.hip`) |\n|---|---|---|---|---|\n")
+        for (name, mb, th, tp, td) in rows:
+            f.write("| %s | %.2f MB | %.1f ms | %.1f ms | **%.1f ms** |\n" % (name, mb, th * 1e3, tp * 1e3, td * 1e3))
+        f.write("\ninto a map (fp32 pyramids, one host thread, the same mosaic both ways): `pf_feed_jpeg` **%.1f keyframes/s**, host decode + `pf_feed` %.1f keyframes/s\n" % (res["feed_jpeg"], res["decode_then_feed"]))

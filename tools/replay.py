@@ -31,7 +31,7 @@ print("Loaded %d frames." % n0)
 assert m.prepare(ds.plane, ds.camera, [p for _, p in first], images=[i for i, _ in first] if a.thread else None)
 it = iter(range(n0, len(ds)))          # obtainFrame consumed the prepare frames (a thread=0 map never renders them, Map2D.cpp:42)
 t0 = time.perf_counter()
-fed = dt.feed_loop(m, lambda: (lambda k: None if k is None else ds.load(k))(next(it, None)), a.fps)
+fed = dt.feed_loop(m, lambda: (lambda k: None if k is None else ds.load(k, encoded=True))(next(it, None)), a.fps)   # .jpg frames: decoded by the map
 m.sync()
 print("fed %d frames in %.2f s; stats %s" % (fed, time.perf_counter() - t0, m.stats()))
 print("save ->", a.out, m.save(a.out))
