@@ -9,6 +9,7 @@
 #include "jpeg_decode.hpp"
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -126,62 +127,56 @@ struct Comp {
 };
 
 // jidctint.c (jpeg_idct_islow): CONST_BITS 13, PASS1_BITS 2.  The zero-AC shortcuts of the original give the same values
-// as the full butterfly and are kept only as shortcuts.
-inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// as the full butterfly and are left out.
+// All of it in 32-bit arithmetic that wraps (unsigned, shifted as signed): libjpeg's C code keeps these sums in a long and its SIMD code in
+// 32-bit lanes; the two agree wherever the stream is one an encoder writes, and a corrupt stream gets the same pixels here and in
+// jpeg_device.hip instead of undefined behaviour.
+typedef uint32_t u32;
+inline int descale(u32 x, int n) { return (int)(x + (1u << (n - 1))) >> n; }
 inline uint8_t limit_idct(int x)
 {
     x &= 1023;                           // RANGE_MASK; the table of jdmaster.c prepare_range_limit_table past CENTERJSAMPLE
     return (uint8_t)(x < 128 ? x + 128 : x < 512 ? 255 : x < 896 ? 0 : x - 896);
 }
 
+// one 8-point pass of jidctint.c on v[0..7]; `sh`: CONST_BITS - PASS1_BITS for the columns, CONST_BITS + PASS1_BITS + 3 for the rows
+inline void idct8(const u32 v[8], int out[8], int sh)
+{
+    constexpr u32 F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+                  F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
+    u32 z2 = v[2], z3 = v[6];
+    u32 z1 = (z2 + z3) * F0_541;
+    u32 tmp2 = z1 - z3 * F1_847, tmp3 = z1 + z2 * F0_765;
+    u32 tmp0 = (v[0] + v[4]) << 13, tmp1 = (v[0] - v[4]) << 13;
+    const u32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = v[7]; tmp1 = v[5]; tmp2 = v[3]; tmp3 = v[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; u32 z4 = tmp1 + tmp3;
+    const u32 z5 = (z3 + z4) * F1_175;
+    tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
+    z1 *= 0u - F0_899; z2 *= 0u - F2_562; z3 *= 0u - F1_961; z4 *= 0u - F0_390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, sh); out[7] = descale(tmp10 - tmp3, sh);
+    out[1] = descale(tmp11 + tmp2, sh); out[6] = descale(tmp11 - tmp2, sh);
+    out[2] = descale(tmp12 + tmp1, sh); out[5] = descale(tmp12 - tmp1, sh);
+    out[3] = descale(tmp13 + tmp0, sh); out[4] = descale(tmp13 - tmp0, sh);
+}
+
 void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride)
 {
-    enum { F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
-           F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172 };
     int ws[64];
     for (int c = 0; c < 8; c++) {
-        const int16_t* i = in + c; const uint16_t* qq = q + c; int* w = ws + c;
-        if (!(i[8] | i[16] | i[24] | i[32] | i[40] | i[48] | i[56])) {
-            const int dc = (int)((unsigned)(i[0] * qq[0]) << 2);
-            for (int r = 0; r < 8; r++) w[8 * r] = dc;
-            continue;
-        }
-        int z2 = i[16] * qq[16], z3 = i[48] * qq[48];
-        int z1 = (z2 + z3) * F0_541;
-        int tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-        z2 = i[0] * qq[0]; z3 = i[32] * qq[32];
-        int tmp0 = (int)((unsigned)(z2 + z3) << 13), tmp1 = (int)((unsigned)(z2 - z3) << 13);
-        const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = i[56] * qq[56]; tmp1 = i[40] * qq[40]; tmp2 = i[24] * qq[24]; tmp3 = i[8] * qq[8];
-        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-        const int z5 = (z3 + z4) * F1_175;
-        tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-        z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
-        z3 += z5; z4 += z5;
-        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        w[0] = descale(tmp10 + tmp3, 11); w[56] = descale(tmp10 - tmp3, 11);
-        w[8] = descale(tmp11 + tmp2, 11); w[48] = descale(tmp11 - tmp2, 11);
-        w[16] = descale(tmp12 + tmp1, 11); w[40] = descale(tmp12 - tmp1, 11);
-        w[24] = descale(tmp13 + tmp0, 11); w[32] = descale(tmp13 - tmp0, 11);
+        u32 v[8]; int o[8];
+        for (int r = 0; r < 8; r++) v[r] = (u32)((int)in[8 * r + c] * (int)q[8 * r + c]);        // DEQUANTIZE: |product| < 2^31
+        idct8(v, o, 11);
+        for (int r = 0; r < 8; r++) ws[8 * r + c] = o[r];
     }
     for (int r = 0; r < 8; r++) {
-        const int* w = ws + 8 * r; uint8_t* o = out + (size_t)r * stride;
-        int z2 = w[2], z3 = w[6];
-        int z1 = (z2 + z3) * F0_541;
-        int tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-        int tmp0 = (int)((unsigned)(w[0] + w[4]) << 13), tmp1 = (int)((unsigned)(w[0] - w[4]) << 13);
-        const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-        tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
-        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-        const int z5 = (z3 + z4) * F1_175;
-        tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-        z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
-        z3 += z5; z4 += z5;
-        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        o[0] = limit_idct(descale(tmp10 + tmp3, 18)); o[7] = limit_idct(descale(tmp10 - tmp3, 18));
-        o[1] = limit_idct(descale(tmp11 + tmp2, 18)); o[6] = limit_idct(descale(tmp11 - tmp2, 18));
-        o[2] = limit_idct(descale(tmp12 + tmp1, 18)); o[5] = limit_idct(descale(tmp12 - tmp1, 18));
-        o[3] = limit_idct(descale(tmp13 + tmp0, 18)); o[4] = limit_idct(descale(tmp13 - tmp0, 18));
+        u32 v[8]; int o[8];
+        for (int k = 0; k < 8; k++) v[k] = (u32)ws[8 * r + k];
+        idct8(v, o, 18);
+        uint8_t* dst = out + (size_t)r * stride;
+        for (int k = 0; k < 8; k++) dst[k] = limit_idct(o[k]);
     }
 }
 
@@ -238,6 +233,7 @@ struct Decoder {
                 if (d[s] != 8) return fail("only 8-bit samples are supported");
                 H = u16(s + 1); W = u16(s + 3); ncomp = d[s + 5];
                 if (W <= 0 || H <= 0) return fail("empty image (DNL is not supported)");
+                if ((unsigned long long)W * (unsigned long long)H > (1ull << 30)) return fail("image of more than 2^30 pixels");      // OpenCV's CV_IO_MAX_IMAGE_PIXELS
                 if (ncomp != 1 && ncomp != 3) return fail("only 1- and 3-component images are supported");
                 if (e - s < (size_t)(6 + 3 * ncomp)) return fail("bad SOF");
                 progressive = m == 0xC2;
@@ -277,6 +273,8 @@ struct Decoder {
                     for (int l = 1; l <= 16; l++) { bits[l] = d[at + l]; nv += bits[l]; }
                     at += 17;
                     if (tc > 1 || th > 3 || nv > 256 || at + nv > e) return fail("bad DHT");
+                    if (!tc)                                  // jdhuff.c jpeg_make_d_derived_tbl: a DC symbol is a bit count of at most 15
+                        for (int i = 0; i < nv; i++) if (d[at + i] > 15) return fail("bad Huffman table");
                     if (!(tc ? ac[th] : dc[th]).build(bits, d + at, nv)) return fail("bad Huffman table");
                     at += nv;
                 }
@@ -559,11 +557,18 @@ bool jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* comps
 
 bool jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols, size_t stride)
 {
-    Decoder dec(data, len);
     if (!data || !bgr) { set_error("jpeg: null buffer"); return false; }
-    if (!dec.read_headers(false) || !dec.reconstruct()) { set_error(dec.err); return false; }
-    if (rows != dec.H || cols != dec.W || stride < (size_t)cols * 3) { set_error("jpeg: the output buffer does not have the image's size"); return false; }
-    return dec.output_bgr(bgr, stride);
+    try {
+        Decoder dec(data, len);
+        if (!dec.read_headers(true)) { set_error(dec.err); return false; }
+        if (rows != dec.H || cols != dec.W || stride < (size_t)cols * 3) { set_error("jpeg: the output buffer does not have the image's size"); return false; }
+        Decoder full(data, len);
+        if (!full.read_headers(false) || !full.reconstruct()) { set_error(full.err); return false; }
+        return full.output_bgr(bgr, stride);
+    } catch (const std::bad_alloc&) {
+        set_error("jpeg: out of memory");
+        return false;
+    }
 }
 
 static void describe(const Decoder& dec, JpegFrame& f)
@@ -639,7 +644,13 @@ static bool ppm_header(const std::vector<uint8_t>& b, int& w, int& h, size_t& at
 }
 
 // cv::imread(filename) for the two formats the file driver feeds from: JPEG (by its SOI) and binary PPM
+static bool read_image_file_checked(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols);
 bool read_image_file(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols)
+{
+    try { return read_image_file_checked(filename, bgr, rows, cols); }
+    catch (const std::bad_alloc&) { set_error(std::string("out of memory reading ") + filename); return false; }
+}
+static bool read_image_file_checked(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols)
 {
     std::vector<uint8_t> b;
     if (!read_file_bytes(filename, b)) return false;

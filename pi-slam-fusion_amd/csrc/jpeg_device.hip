@@ -30,28 +30,29 @@ constexpr size_t kHeaderBytes = 1024;
 
 namespace {
 
-__device__ inline int dsc(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+typedef uint32_t u32;                          // sums that wrap, shifted as signed: jpeg_decode.cpp's idct8, statement for statement
+__device__ inline int dsc(u32 x, int n) { return (int)(x + (1u << (n - 1))) >> n; }
 __device__ inline int lim(int x)              // jdmaster.c prepare_range_limit_table, IDCT part, after "& RANGE_MASK"
 {
     x &= 1023;
     return x < 128 ? x + 128 : x < 512 ? 255 : x < 896 ? 0 : x - 896;
 }
 
-// jidctint.c: the 8-point pass on values already in registers; `s0` / `sh`: pre-shift of the even DC pair and the final descale
-__device__ inline void idct8(const int v[8], int out[8], int sh)
+// jidctint.c: one 8-point pass on values in registers; `sh`: the pass's descale
+__device__ inline void idct8(const u32 v[8], int out[8], int sh)
 {
-    constexpr int F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
+    constexpr u32 F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299, F1_847 = 15137,
                   F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-    int z2 = v[2], z3 = v[6];
-    int z1 = (z2 + z3) * F0_541;
-    int tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-    int tmp0 = (int)((unsigned)(v[0] + v[4]) << 13), tmp1 = (int)((unsigned)(v[0] - v[4]) << 13);
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    u32 z2 = v[2], z3 = v[6];
+    u32 z1 = (z2 + z3) * F0_541;
+    u32 tmp2 = z1 - z3 * F1_847, tmp3 = z1 + z2 * F0_765;
+    u32 tmp0 = (v[0] + v[4]) << 13, tmp1 = (v[0] - v[4]) << 13;
+    const u32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = v[7]; tmp1 = v[5]; tmp2 = v[3]; tmp3 = v[1];
-    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * F1_175;
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; u32 z4 = tmp1 + tmp3;
+    const u32 z5 = (z3 + z4) * F1_175;
     tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
-    z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
+    z1 *= 0u - F0_899; z2 *= 0u - F2_562; z3 *= 0u - F1_961; z4 *= 0u - F0_390;
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
     out[0] = dsc(tmp10 + tmp3, sh); out[7] = dsc(tmp10 - tmp3, sh);
@@ -88,15 +89,15 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const JpegDevFrame* __restric
         }
     }
     __syncthreads();
-    int v[8], o[8];
+    u32 v[8]; int o[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) v[r] = w[8 * r + j];                     // column j
+    for (int r = 0; r < 8; r++) v[r] = (u32)w[8 * r + j];                // column j
     idct8(v, o, 11);                                                     // CONST_BITS - PASS1_BITS
 #pragma unroll
     for (int r = 0; r < 8; r++) w[8 * r + j] = o[r];                     // in place: the thread owns the column
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = w[8 * j + k];                     // row j
+    for (int k = 0; k < 8; k++) v[k] = (u32)w[8 * j + k];                // row j
     idct8(v, o, 18);                                                     // CONST_BITS + PASS1_BITS + 3
     if (live) {
         const unsigned by = b / (unsigned)C.bw, bx = b - by * (unsigned)C.bw;

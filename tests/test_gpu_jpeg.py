@@ -95,3 +95,31 @@ def test_feed_jpeg_equals_oracle_fed_the_reference_decoders_pixels(pf, orc, thre
     assert not m.feed_jpeg(b"\xff\xd8\xff", poses[0])
     m.close()
     assert np.array_equal(got, ref)
+
+
+def test_damaged_streams_get_the_same_pixels_on_both_back_ends(pf):
+    """whatever the host decoder makes of a damaged stream (libjpeg's policy: zero bits after the end of the data, wrapping sums), the device
+    back end makes the same of it -- and refuses what the host refuses"""
+    from test_jpeg import mutated
+    import torch
+    streams = [s for _, s, _ in vectors()]
+    same = refused = 0
+    for b in mutated(streams, 9, 600):
+        try:
+            r, c, _ = pf.jpeg_info(b)
+        except ValueError:
+            refused += 1
+            continue
+        if r * c > 1 << 22:
+            continue
+        try:
+            host = pf.decode_jpeg(b)
+        except ValueError:
+            out = torch.zeros((r, c, 3), dtype=torch.uint8, device="cuda")
+            with pytest.raises(ValueError):
+                pf.decode_jpeg_device(b, out.data_ptr(), r, c)
+            refused += 1
+            continue
+        assert np.array_equal(on_device(pf, b), host)
+        same += 1
+    assert same > 150 and refused > 50
