@@ -127,6 +127,10 @@ int     pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, in
  * is decoded straight into HBM on the map's stream and rendered from there (thread=0 maps; a thread=1 map decodes on the
  * host and queues the pixels as pf_feed does).  Returns what pf_feed returns.                                          */
 int     pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7]);
+/* n keyframes at once: their Huffman passes run side by side on `threads` host threads (0: one per frame; batches of 16), then
+ * the frames are uploaded, finished on the GPU and fed in the order given -- the mosaic is the one n pf_feed_jpeg calls build.
+ * results[i] (may be NULL) = what pf_feed_jpeg returns for frame i; returns the number of frames fed.                  */
+int     pf_feed_jpeg_batch(pf_map* m, int n, const uint8_t* const* data, const size_t* len, const double* poses7, int threads, int* results);
 /* save() without the file: whole-mosaic collapse into caller memory.  Call
  * with bgr=NULL to query rows/cols/origin tile.                            */
 int     pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tile_x0, int* tile_y0);

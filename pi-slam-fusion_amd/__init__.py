@@ -90,6 +90,7 @@ def lib():
     L.pf_jpeg_decode_bgr.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int]
     L.pf_jpeg_decode_device.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int, vp]
     L.pf_feed_jpeg.argtypes = [vp, C.c_char_p, C.c_size_t, dp]
+    L.pf_feed_jpeg_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), dp, C.c_int, ip]
     L.pf_num_levels.argtypes = [vp]
     L.pf_pyramid_type.argtypes = [vp]
     L.pf_grid.argtypes = [vp, ip, dp]
@@ -328,6 +329,17 @@ class Map2D:
         p, pp = _pose(pose)
         b = bytes(data)
         return bool(lib().pf_feed_jpeg(self._h, b, len(b), pp))
+
+    def feed_jpeg_batch(self, streams, poses, threads=0):
+        """n .jpg keyframes at once: Huffman passes on `threads` host threads (0: one per frame), the rest on the GPU, fed in order.
+        Returns the list of per-frame results (what feed_jpeg returns)."""
+        n = len(streams)
+        keep = [bytes(s) for s in streams]
+        data = (C.c_char_p * n)(*keep); lens = (C.c_size_t * n)(*[len(s) for s in keep])
+        pp = (C.c_double * (7 * n))(*[float(v) for p in poses for v in p])
+        res = (C.c_int * n)()
+        lib().pf_feed_jpeg_batch(self._h, n, data, lens, pp, threads, res)
+        return [bool(r) for r in res]
 
     def read_last_frame(self):
         """test hook: bytes of the most recently uploaded host frame as they lie in HBM"""

@@ -5,6 +5,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include <mutex>
 #include <new>
 
@@ -135,6 +139,63 @@ int pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7
     if (!m->jpeg.decode_to(data, len, (uint8_t*)frame, rows, cols, (void*)m->impl.stream())) return 0;
     pf_image img = { rows, cols, PF_8UC3, frame, 0 };
     return m->impl.feed(&img, pose, true);
+}
+int pf_feed_jpeg_batch(pf_map* m, int n, const uint8_t* const* data, const size_t* len, const double* poses7, int threads, int* results)
+{
+    if (!m || n < 1 || !data || !len || !poses7) return 0;
+    int fed = 0;
+    if (results) for (int i = 0; i < n; i++) results[i] = 0;
+    const bool device = !m->threaded;
+    if (device && (!m->impl.ok() || !m->impl.use_device())) { pf::set_error("pf_feed_jpeg_batch: no device"); return 0; }
+    for (int base = 0; base < n; base += pf::JpegDevice::kSlots) {
+        const int cnt = std::min(n - base, (int)pf::JpegDevice::kSlots);
+        if (!device) {                                    // threaded map: whole decodes side by side, host pixels queued in order
+            std::vector<std::vector<uint8_t>> px((size_t)cnt);
+            std::vector<int> rows(cnt, 0), cols(cnt, 0); std::vector<unsigned char> ok(cnt, 0);
+            std::atomic<int> next(0);
+            auto work = [&]() {
+                for (int i = next++; i < cnt; i = next++) {
+                    int comps = 0;
+                    if (!data[base + i] || !pf::jpeg_info(data[base + i], len[base + i], &rows[i], &cols[i], &comps)) continue;
+                    px[i].resize((size_t)rows[i] * cols[i] * 3);
+                    ok[i] = pf::jpeg_decode_bgr(data[base + i], len[base + i], px[i].data(), rows[i], cols[i], (size_t)cols[i] * 3) ? 1 : 0;
+                }
+            };
+            const int nt = threads <= 0 || threads > cnt ? cnt : threads;
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+            for (int i = 0; i < cnt; i++) {
+                if (!ok[i]) { pf::set_error("pf_feed_jpeg_batch: a frame of the batch could not be decoded"); continue; }
+                pf_image img = { rows[i], cols[i], PF_8UC3, px[i].data(), 0 };
+                const int r = m->impl.feed(&img, poses7 + 7 * (size_t)(base + i), false);
+                if (results) results[base + i] = r;
+                fed += r != 0;
+            }
+            continue;
+        }
+        unsigned char ok[pf::JpegDevice::kSlots];
+        if (!m->jpeg.stage_batch(cnt, data + base, len + base, 0, 0, threads, ok)) return fed;
+        for (int i = 0; i < cnt; i++) {
+            if (!ok[i]) { m->jpeg.submit(i, nullptr, nullptr); continue; }          // leaves the frame's message in pf_last_error()
+            int rows = 0, cols = 0;
+            m->jpeg.staged_size(i, &rows, &cols);
+            const size_t bytes = (size_t)rows * cols * 3;
+            if (m->jpeg_frame_cap < bytes) {
+                if (!m->impl.sync()) return fed;
+                if (!pf::jpeg_frames_resize(m->jpeg_frame, 3, bytes)) return fed;
+                m->jpeg_frame_cap = bytes;
+            }
+            void* frame = m->jpeg_frame[m->jpeg_next++ % 3];
+            if (!m->jpeg.submit(i, (uint8_t*)frame, (void*)m->impl.stream())) continue;
+            pf_image img = { rows, cols, PF_8UC3, frame, 0 };
+            const int r = m->impl.feed(&img, poses7 + 7 * (size_t)(base + i), true);
+            if (results) results[base + i] = r;
+            fed += r != 0;
+        }
+    }
+    return fed;
 }
 int pf_save_to_memory(pf_map* m, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return m && rows && cols && tx0 && ty0 && m->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }

@@ -6,7 +6,8 @@
 #include <vector>
 
 namespace pf {
-void set_error(const std::string& msg);          // fusion_map.cpp: what pf_last_error() returns
+void set_error(const std::string& msg);          // fusion_map.cpp: what pf_last_error() returns (per thread)
+const char* last_error();
 bool jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* comps);
 // 8-bit BGR, rows x cols as jpeg_info reports them, `stride` bytes per row
 bool jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols, size_t stride);

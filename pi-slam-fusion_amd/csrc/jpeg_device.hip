@@ -8,8 +8,11 @@
 // (4:2:0).  A 4000 x 3000 4:2:0 frame: 54 MB + 54 MB.
 #include "jpeg_device.hpp"
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstddef>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace pf {
 
@@ -267,16 +270,19 @@ JpegDevice::~JpegDevice()
     if (planes_) (void)hipFree(planes_);
 }
 
-bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream)
+// Host side of a frame, step 1 (calling thread): the geometry, and a pinned buffer that the previous upload out of it has left
+bool JpegDevice::prepare(int i, const uint8_t* data, size_t len, int rows, int cols)
 {
-    hipStream_t st = (hipStream_t)stream;
-    JpegFrame f;
-    if (!data || !dev_bgr) { set_error("jpeg device: null buffer"); return false; }
-    if (!jpeg_frame_info(data, len, f)) return false;
-    if (f.rows != rows || f.cols != cols) { set_error("jpeg device: the output buffer does not have the image's size"); return false; }
-    const size_t need = kHeaderBytes + f.coef_count * sizeof(int16_t);
-    Slot& s = slot_[next_]; next_ ^= 1;
+    if (i < 0 || i >= kSlots) { set_error("jpeg device: no such staging buffer"); return false; }
+    Slot& s = slot_[i];
+    s.staged = false;
+    if (!data) { set_error("jpeg device: null buffer"); return false; }
+    if (!jpeg_frame_info(data, len, s.f)) return false;
+    if (rows > 0 && (s.f.rows != rows || s.f.cols != cols)) { set_error("jpeg device: the output buffer does not have the image's size"); return false; }
+    if (s.f.coef_count >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
+    const size_t need = kHeaderBytes + s.f.coef_count * sizeof(int16_t);
     if (s.done && s.used && !hip_ok(hipEventSynchronize((hipEvent_t)s.done), "wait for the staging buffer")) return false;
+    s.used = false;
     if (s.cap < need) {
         if (s.host) (void)hipHostFree(s.host);
         s.host = nullptr; s.cap = 0;
@@ -284,8 +290,29 @@ bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, in
         s.cap = need;
     }
     if (!s.done) { hipEvent_t e; if (!hip_ok(hipEventCreateWithFlags(&e, hipEventDisableTiming), "event")) return false; s.done = e; }
-    if (!jpeg_entropy_decode(data, len, f, (int16_t*)((char*)s.host + kHeaderBytes), f.coef_count)) return false;
+    return true;
+}
 
+// ... step 2 (any thread; no HIP call): markers + Huffman into the pinned buffer.  An error message stays in the slot.
+bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
+{
+    Slot& s = slot_[i];
+    s.staged = jpeg_entropy_decode(data, len, s.f, (int16_t*)((char*)s.host + kHeaderBytes), s.f.coef_count);
+    if (!s.staged) s.err = last_error();
+    return s.staged;
+}
+
+// ... step 3 (calling thread): upload and the two kernels on `stream`
+bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Slot& s = slot_[i];
+    if (!s.staged) { set_error(s.err.empty() ? "jpeg device: frame was not staged" : s.err); return false; }
+    if (!dev_bgr) { set_error("jpeg device: null buffer"); return false; }
+    s.staged = false;
+    const JpegFrame& f = s.f;
+    const int rows = f.rows, cols = f.cols;
+    const size_t need = kHeaderBytes + f.coef_count * sizeof(int16_t);
     JpegDevFrame h;
     std::memset(&h, 0, sizeof(h));
     h.rows = f.rows; h.cols = f.cols; h.ncomp = f.ncomp; h.ycc = f.ycc ? 1 : 0;
@@ -301,7 +328,7 @@ bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, in
         plane_bytes += (size_t)k.bw * 8 * k.bh * 8;
     }
     for (int c = f.ncomp; c < 4; c++) h.block_first[c] = blocks;
-    if (f.coef_count >= (1ull << 31) || plane_bytes >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
+    if (plane_bytes >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
     std::memcpy(s.host, &h, sizeof(h));
 
     if (dev_cap_ < need) {
@@ -333,6 +360,34 @@ bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, in
     else hipLaunchKernelGGL(k_jpeg_colour, dim3((unsigned)((cols + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
     last_ = { f.coef_count * sizeof(int16_t), plane_bytes, (size_t)rows * cols * 3 };
     return hip_ok(hipGetLastError(), "kernel launch");
+}
+
+bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream)
+{
+    if (!dev_bgr) { set_error("jpeg device: null buffer"); return false; }
+    const int i = next_; next_ ^= 1;              // two buffers: this frame's Huffman pass overlaps the previous frame's upload
+    if (!prepare(i, data, len, rows, cols)) return false;
+    if (!entropy(i, data, len)) { set_error(slot_[i].err); return false; }
+    return submit(i, dev_bgr, stream);
+}
+
+// n frames: step 1 for each, then their Huffman passes side by side on host threads; the caller submits them in the order it wants
+bool JpegDevice::stage_batch(int n, const uint8_t* const* data, const size_t* len, int rows, int cols, int threads, unsigned char* ok)
+{
+    if (n < 1 || n > kSlots) { set_error("jpeg device: a batch holds 1 to 16 frames"); return false; }
+    for (int i = 0; i < n; i++) {
+        ok[i] = prepare(i, data[i], len[i], rows, cols) ? 1 : 0;
+        if (!ok[i]) slot_[i].err = last_error();
+    }
+    if (threads <= 0 || threads > n) threads = n;
+    std::atomic<int> next(0);
+    auto work = [&]() { for (int i = next++; i < n; i = next++) if (ok[i]) ok[i] = entropy(i, data[i], len[i]) ? 1 : 0; };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    next_ = 0;
+    return true;
 }
 
 }  // namespace pf

@@ -9,16 +9,24 @@ namespace pf {
 // `stream` (a hipStream_t); the BGR8 frame, rows * cols * 3 bytes packed, is complete in `dev_bgr` in stream order.  Not thread-safe.
 class JpegDevice {
 public:
+    enum { kSlots = 16 };
     struct Bytes { size_t coefficients, planes, frame; };
     JpegDevice() {}
     ~JpegDevice();
     JpegDevice(const JpegDevice&) = delete;
     JpegDevice& operator=(const JpegDevice&) = delete;
     bool decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream);
+    // A batch: the Huffman passes of n <= kSlots frames side by side on `threads` host threads (0: one each); ok[i] says whether frame i is
+    // staged (its message otherwise comes out of submit).  Then submit(i, ...) per frame, in the order wanted.  rows = 0: any size.
+    bool stage_batch(int n, const uint8_t* const* data, const size_t* len, int rows, int cols, int threads, unsigned char* ok);
+    bool submit(int i, uint8_t* dev_bgr, void* stream);
+    void staged_size(int i, int* rows, int* cols) const { *rows = slot_[i].f.rows; *cols = slot_[i].f.cols; }
     Bytes last_bytes() const { return last_; }          // of the most recent frame: what the two kernels read and wrote
 private:
-    struct Slot { void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false; };
-    Slot   slot_[2];
+    struct Slot { void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false, staged = false; JpegFrame f; std::string err; };
+    bool prepare(int i, const uint8_t* data, size_t len, int rows, int cols);
+    bool entropy(int i, const uint8_t* data, size_t len);
+    Slot   slot_[kSlots];
     int    next_ = 0;
     void*  dev_ = nullptr;    size_t dev_cap_ = 0;
     void*  planes_ = nullptr; size_t planes_cap_ = 0;

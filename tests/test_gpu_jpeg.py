@@ -123,3 +123,32 @@ def test_damaged_streams_get_the_same_pixels_on_both_back_ends(pf):
         assert np.array_equal(on_device(pf, b), host)
         same += 1
     assert same > 150 and refused > 50
+
+
+@pytest.mark.parametrize("thread", [False, True])
+def test_feed_jpeg_batch_builds_the_same_mosaic_as_one_by_one(pf, thread):
+    Image = pytest.importorskip("PIL.Image")
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    poses = jitter_poses(21, seed=8)
+    streams = []
+    for k in range(len(poses)):
+        b = io.BytesIO()
+        Image.fromarray(wl.noise_frame(480, 640, 70 + k)[:, :, ::-1].copy()).save(b, "JPEG", quality=80, subsampling=[2, 1, 0][k % 3])
+        streams.append(b.getvalue())
+    mos = []
+    for batch in (False, True):
+        m = pf.Map2D.create(pf.TypeMultiBandCPU, thread, max_queue=64)
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:3])
+        if batch:
+            bad = list(streams); bad[7] = streams[7][:40]; bad[9] = b"junk"           # a broken frame leaves the others alone
+            res = m.feed_jpeg_batch(bad, poses, threads=4)                            # 21 frames: a batch of 16 and one of 5
+            assert res == [k not in (7, 9) for k in range(len(poses))]
+        else:
+            for k in range(len(poses)):
+                if k not in (7, 9):
+                    assert m.feed_jpeg(streams[k], poses[k])
+        m.sync()
+        mos.append(m.save_to_memory()[0])
+        m.close()
+    assert np.array_equal(mos[0], mos[1])

@@ -66,13 +66,26 @@ for name, kw in [("4:2:0 q90", dict(quality=90, subsampling=2)), ("4:2:0 q75", d
 poses = wl.serpentine(cam, 100.0, a.frames + 4)
 b = io.BytesIO(); Image.fromarray(pic).save(b, "JPEG", quality=90, subsampling=2); s = b.getvalue()
 res = {}
-for mode in ("feed_jpeg", "decode_then_feed"):
+for mode in ("feed_jpeg", "decode_then_feed", "batch4", "batch8", "batch16"):
     m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1)
     assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:4])
     for k in range(2):
-        m.feed_jpeg(s, poses[k]) if mode == "feed_jpeg" else m.feed(pf.decode_jpeg(s), poses[k])
+        m.feed(pf.decode_jpeg(s), poses[k]) if mode == "decode_then_feed" else m.feed_jpeg(s, poses[k])
     m.sync()
     t = time.perf_counter()
+    if mode.startswith("batch"):
+        nb = int(mode[5:]); done = 0
+        frames_b = 4 * nb
+        poses_b = wl.serpentine(cam, 100.0, frames_b + nb + 4)
+        assert all(m.feed_jpeg_batch([s] * nb, poses_b[2:2 + nb], threads=nb))       # untimed: the batch's pinned buffers are allocated here
+        m.sync()
+        t = time.perf_counter()
+        for k in range(2 + nb, 2 + nb + frames_b, nb):
+            assert all(m.feed_jpeg_batch([s] * nb, poses_b[k:k + nb], threads=nb)); done += nb
+        m.sync()
+        res[mode] = done / (time.perf_counter() - t)
+        m.close()
+        continue
     for k in range(2, 2 + a.frames):
         m.feed_jpeg(s, poses[k]) if mode == "feed_jpeg" else m.feed(pf.decode_jpeg(s), poses[k])
     m.sync()
@@ -81,9 +94,11 @@ for mode in ("feed_jpeg", "decode_then_feed"):
     m.close()
 assert np.array_equal(res["feed_jpeg_img"], res["decode_then_feed_img"])
 print("into a map: pf_feed_jpeg %.1f keyframes/s, host decode + pf_feed %.1f keyframes/s (one host thread; same mosaic)" % (res["feed_jpeg"], res["decode_then_feed"]), flush=True)
+print("pf_feed_jpeg_batch: %s keyframes/s with 4 / 8 / 16 frames and threads per batch (%d host cores)" % (" / ".join("%.0f" % res["batch%d" % n] for n in (4, 8, 16)), os.cpu_count()), flush=True)
 if a.md:
     with open(a.md, "w") as f:
         f.write("| stream (4000 x 3000) | size | host decode (`jpeg_decode.cpp`) | libjpeg-turbo via Pillow (SIMD) | split decode: Huffman on the host, the rest on the GPU (`jpeg_device.hip`) |\n|---|---|---|---|---|\n")
         for (name, mb, th, tp, td) in rows:
             f.write("| %s | %.2f MB | %.1f ms | %.1f ms | **%.1f ms** |\n" % (name, mb, th * 1e3, tp * 1e3, td * 1e3))
         f.write("\ninto a map (fp32 pyramids, one host thread, the same mosaic both ways): `pf_feed_jpeg` **%.1f keyframes/s**, host decode + `pf_feed` %.1f keyframes/s\n" % (res["feed_jpeg"], res["decode_then_feed"]))
+        f.write("\n`pf_feed_jpeg_batch` (Huffman passes of a batch side by side, %d host cores): **%s keyframes/s** with 4 / 8 / 16 frames and threads per batch\n" % (os.cpu_count(), " / ".join("%.0f" % res["batch%d" % n] for n in (4, 8, 16))))
