@@ -123,9 +123,9 @@ int     pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int ro
  * byte-equal to pf_jpeg_decode_bgr.  dev_bgr: rows*cols*3 bytes of device memory, complete in the order of `hip_stream`
  * (a hipStream_t, NULL = the default stream); the call returns when the work is queued.                               */
 int     pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream);
-/* Map2D::feed(cv::imread(imgfile), pose) in one call (backup/map2dfusion.cpp:129-135 + Map2DFusion.cpp:313-327): the frame
- * is decoded straight into HBM on the map's stream and rendered from there (thread=0 maps; a thread=1 map decodes on the
- * host and queues the pixels as pf_feed does).  Returns what pf_feed returns.                                          */
+/* Map2D::feed(cv::imread(imgfile), pose) in one call (backup/map2dfusion.cpp:129-135 + Map2DFusion.cpp:313-327): markers and
+ * Huffman on the calling thread, then the frame is finished on the GPU straight into the slot in HBM a host frame would have
+ * been uploaded to, and queued (thread=1) or rendered (thread=0) from there.  Returns what pf_feed returns.             */
 int     pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7]);
 /* n keyframes at once: their Huffman passes run side by side on `threads` host threads (0: one per frame; batches of 16), then
  * the frames are uploaded, finished on the GPU and fed in the order given -- the mosaic is the one n pf_feed_jpeg calls build.

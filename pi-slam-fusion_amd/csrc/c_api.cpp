@@ -16,16 +16,10 @@ using pf::FusionMap;
 
 struct pf_map {
     FusionMap impl;
-    bool threaded;
-    // pf_feed_jpeg: the decoder's device back end and the keyframes it writes (a ring: a frame is read by the launch its feed queues, on
-    // the stream the decoder's kernels are queued on, so one buffer would do; three keep that from depending on the engine's internals)
-    pf::JpegDevice jpeg;
-    void* jpeg_frame[3] = { nullptr, nullptr, nullptr }; size_t jpeg_frame_cap = 0; unsigned jpeg_next = 0;
-    pf_map(int t, bool th, const pf_options& o) : impl(t, th, o), threaded(th) {}
-    ~pf_map();
+    pf::JpegDevice jpeg;          // pf_feed_jpeg: the decoder's device back end (staging buffers, coefficient and plane buffers)
+    pf_map(int t, bool th, const pf_options& o) : impl(t, th, o) {}
+    ~pf_map() { if (impl.ok() && impl.use_device()) impl.sync(); }          // the decoder's buffers go before the engine: nothing may still read them
 };
-
-pf_map::~pf_map() { if (impl.ok() && impl.use_device()) impl.sync(); pf::jpeg_frames_resize(jpeg_frame, 3, 0); }
 
 extern "C" {
 
@@ -117,80 +111,37 @@ int pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int ro
     std::lock_guard<std::mutex> l(mu);
     return rows > 0 && cols > 0 && dec->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
 }
+// one staged frame (JpegDevice slot i) into the map: the frame's slot in HBM is filled by the decoder's upload + kernels on the map's stream
+static int feed_staged_jpeg(pf_map* m, int i, const double pose[7])
+{
+    int rows = 0, cols = 0;
+    m->jpeg.staged_size(i, &rows, &cols);
+    const FusionMap::FrameProducer fill = [m, i](void* dev, hipStream_t st) { return m->jpeg.submit(i, (uint8_t*)dev, (void*)st); };
+    pf_image img = { rows, cols, PF_8UC3, nullptr, 0 };
+    return m->impl.feed(&img, pose, false, &fill);
+}
 int pf_feed_jpeg(pf_map* m, const uint8_t* data, size_t len, const double pose[7])
 {
     if (!m || !data || !pose) return 0;
-    int rows = 0, cols = 0, comps = 0;
-    if (!pf::jpeg_info(data, len, &rows, &cols, &comps)) return 0;
-    if (m->threaded) {                                    // Map2D::feed on a threaded map takes host pixels (the queue owns a copy)
-        std::vector<uint8_t> px((size_t)rows * cols * 3);
-        if (!pf::jpeg_decode_bgr(data, len, px.data(), rows, cols, (size_t)cols * 3)) return 0;
-        pf_image img = { rows, cols, PF_8UC3, px.data(), 0 };
-        return m->impl.feed(&img, pose, false);
-    }
     if (!m->impl.ok() || !m->impl.use_device()) { pf::set_error("pf_feed_jpeg: no device"); return 0; }
-    const size_t bytes = (size_t)rows * cols * 3;
-    if (m->jpeg_frame_cap < bytes) {
-        if (!m->impl.sync()) return 0;
-        if (!pf::jpeg_frames_resize(m->jpeg_frame, 3, bytes)) return 0;
-        m->jpeg_frame_cap = bytes;
-    }
-    void* frame = m->jpeg_frame[m->jpeg_next++ % 3];
-    if (!m->jpeg.decode_to(data, len, (uint8_t*)frame, rows, cols, (void*)m->impl.stream())) return 0;
-    pf_image img = { rows, cols, PF_8UC3, frame, 0 };
-    return m->impl.feed(&img, pose, true);
+    unsigned char ok = 0;
+    const int i = m->jpeg.stage_one(data, len, &ok);          // markers + Huffman on this thread, outside the map's lock
+    if (!ok) { m->jpeg.submit(i, nullptr, nullptr); return 0; }          // leaves the frame's message in pf_last_error()
+    return feed_staged_jpeg(m, i, pose);
 }
 int pf_feed_jpeg_batch(pf_map* m, int n, const uint8_t* const* data, const size_t* len, const double* poses7, int threads, int* results)
 {
     if (!m || n < 1 || !data || !len || !poses7) return 0;
     int fed = 0;
     if (results) for (int i = 0; i < n; i++) results[i] = 0;
-    const bool device = !m->threaded;
-    if (device && (!m->impl.ok() || !m->impl.use_device())) { pf::set_error("pf_feed_jpeg_batch: no device"); return 0; }
+    if (!m->impl.ok() || !m->impl.use_device()) { pf::set_error("pf_feed_jpeg_batch: no device"); return 0; }
     for (int base = 0; base < n; base += pf::JpegDevice::kSlots) {
         const int cnt = std::min(n - base, (int)pf::JpegDevice::kSlots);
-        if (!device) {                                    // threaded map: whole decodes side by side, host pixels queued in order
-            std::vector<std::vector<uint8_t>> px((size_t)cnt);
-            std::vector<int> rows(cnt, 0), cols(cnt, 0); std::vector<unsigned char> ok(cnt, 0);
-            std::atomic<int> next(0);
-            auto work = [&]() {
-                for (int i = next++; i < cnt; i = next++) {
-                    int comps = 0;
-                    if (!data[base + i] || !pf::jpeg_info(data[base + i], len[base + i], &rows[i], &cols[i], &comps)) continue;
-                    px[i].resize((size_t)rows[i] * cols[i] * 3);
-                    ok[i] = pf::jpeg_decode_bgr(data[base + i], len[base + i], px[i].data(), rows[i], cols[i], (size_t)cols[i] * 3) ? 1 : 0;
-                }
-            };
-            const int nt = threads <= 0 || threads > cnt ? cnt : threads;
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nt; t++) pool.emplace_back(work);
-            work();
-            for (auto& t : pool) t.join();
-            for (int i = 0; i < cnt; i++) {
-                if (!ok[i]) { pf::set_error("pf_feed_jpeg_batch: a frame of the batch could not be decoded"); continue; }
-                pf_image img = { rows[i], cols[i], PF_8UC3, px[i].data(), 0 };
-                const int r = m->impl.feed(&img, poses7 + 7 * (size_t)(base + i), false);
-                if (results) results[base + i] = r;
-                fed += r != 0;
-            }
-            continue;
-        }
         unsigned char ok[pf::JpegDevice::kSlots];
         if (!m->jpeg.stage_batch(cnt, data + base, len + base, 0, 0, threads, ok)) return fed;
         for (int i = 0; i < cnt; i++) {
-            if (!ok[i]) { m->jpeg.submit(i, nullptr, nullptr); continue; }          // leaves the frame's message in pf_last_error()
-            int rows = 0, cols = 0;
-            m->jpeg.staged_size(i, &rows, &cols);
-            const size_t bytes = (size_t)rows * cols * 3;
-            if (m->jpeg_frame_cap < bytes) {
-                if (!m->impl.sync()) return fed;
-                if (!pf::jpeg_frames_resize(m->jpeg_frame, 3, bytes)) return fed;
-                m->jpeg_frame_cap = bytes;
-            }
-            void* frame = m->jpeg_frame[m->jpeg_next++ % 3];
-            if (!m->jpeg.submit(i, (uint8_t*)frame, (void*)m->impl.stream())) continue;
-            pf_image img = { rows, cols, PF_8UC3, frame, 0 };
-            const int r = m->impl.feed(&img, poses7 + 7 * (size_t)(base + i), true);
+            if (!ok[i]) { m->jpeg.submit(i, nullptr, nullptr); continue; }
+            const int r = feed_staged_jpeg(m, i, poses7 + 7 * (size_t)(base + i));
             if (results) results[base + i] = r;
             fed += r != 0;
         }

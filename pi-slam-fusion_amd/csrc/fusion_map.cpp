@@ -465,7 +465,7 @@ bool FusionMap::upload(const pf_image* img, int slot)
 }
 
 // MultiBandMap2DCPU::feed (.cpp:288-309)
-bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr)
+bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr, const FrameProducer* produce)
 {
     if (!init_ok_) { set_error("feed: no device"); return false; }
     Section sec(this, T_FEED);
@@ -504,6 +504,15 @@ bool FusionMap::feed(const pf_image* img, const double pose7[7], bool device_ptr
                     f.slot = acquire_slot((size_t)img->rows * (size_t)f.step);
                     if (f.slot < 0 || !upload(img, f.slot)) return false;
                 }
+            } else if (produce) {
+                f.step = (long)img->cols * f.cn;
+                if (frame_bytes(img->rows, img->cols, f.step, f.cn) < 8) { set_error("feed: frame smaller than 8 bytes"); return false; }
+                f.slot = acquire_slot((size_t)img->rows * (size_t)f.step);
+                if (f.slot < 0 || !(*produce)(slots_[f.slot].dev, stream_)) return false;
+                // the producer's work sits on stream_ ahead of the launch that reads the slot; should the frame be dropped from the
+                // queue instead, the slot's next user (possibly a blocking upload) has to wait for that work all the same
+                HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_));
+                slots_[f.slot].pending = true;
             }
         }
     }

@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -93,7 +94,11 @@ public:
     bool ok() const { return init_ok_; }
 
     bool prepare(const double plane[7], const double cam[6], int n, const pf_image* imgs, const double* poses7);
-    bool feed(const pf_image* img, const double pose[7], bool device_ptr);
+    // `produce` (img->data == nullptr): the frame's pixels are written into HBM by the caller's own work -- it is handed the frame's slot
+    // and the stream that work has to be queued on (pf_feed_jpeg: the decoder's upload and kernels); the frame is then queued or rendered
+    // exactly as a host frame that feed() uploaded
+    typedef std::function<bool(void* dev, hipStream_t stream)> FrameProducer;
+    bool feed(const pf_image* img, const double pose[7], bool device_ptr, const FrameProducer* produce = nullptr);
     unsigned queue_size();
     long read_back_last_frame(void* out, size_t cap);
     bool sync();

@@ -252,14 +252,6 @@ bool hip_ok(hipError_t e, const char* what)
 
 }  // namespace
 
-bool jpeg_frames_resize(void** bufs, int n, size_t bytes)
-{
-    for (int i = 0; i < n; i++) { if (bufs[i]) (void)hipFree(bufs[i]); bufs[i] = nullptr; }
-    for (int i = 0; bytes && i < n; i++)
-        if (!hip_ok(hipMalloc(&bufs[i], bytes), "keyframe buffer")) return false;
-    return true;
-}
-
 JpegDevice::~JpegDevice()
 {
     for (auto& s : slot_) {
@@ -369,6 +361,15 @@ bool JpegDevice::decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, in
     if (!prepare(i, data, len, rows, cols)) return false;
     if (!entropy(i, data, len)) { set_error(slot_[i].err); return false; }
     return submit(i, dev_bgr, stream);
+}
+
+int JpegDevice::stage_one(const uint8_t* data, size_t len, unsigned char* ok)
+{
+    const int i = next_; next_ ^= 1;
+    *ok = prepare(i, data, len, 0, 0) ? 1 : 0;
+    if (!*ok) slot_[i].err = last_error();
+    else *ok = entropy(i, data, len) ? 1 : 0;
+    return i;
 }
 
 // n frames: step 1 for each, then their Huffman passes side by side on host threads; the caller submits them in the order it wants

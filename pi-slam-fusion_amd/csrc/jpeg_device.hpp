@@ -18,6 +18,8 @@ public:
     bool decode_to(const uint8_t* data, size_t len, uint8_t* dev_bgr, int rows, int cols, void* stream);
     // A batch: the Huffman passes of n <= kSlots frames side by side on `threads` host threads (0: one each); ok[i] says whether frame i is
     // staged (its message otherwise comes out of submit).  Then submit(i, ...) per frame, in the order wanted.  rows = 0: any size.
+    // one frame, alternating between two staging buffers: returns the buffer's index for submit()
+    int  stage_one(const uint8_t* data, size_t len, unsigned char* ok);
     bool stage_batch(int n, const uint8_t* const* data, const size_t* len, int rows, int cols, int threads, unsigned char* ok);
     bool submit(int i, uint8_t* dev_bgr, void* stream);
     void staged_size(int i, int* rows, int* cols) const { *rows = slot_[i].f.rows; *cols = slot_[i].f.cols; }
@@ -32,8 +34,5 @@ private:
     void*  planes_ = nullptr; size_t planes_cap_ = 0;
     Bytes  last_ = { 0, 0, 0 };
 };
-
-// (re)allocates `n` device buffers of `bytes` each (0: frees them)
-bool jpeg_frames_resize(void** bufs, int n, size_t bytes);
 
 }  // namespace pf
