@@ -90,6 +90,7 @@ def lib():
     L.pf_jpeg_decode_bgr.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int]
     L.pf_jpeg_decode_device.argtypes = [C.c_char_p, C.c_size_t, vp, C.c_int, C.c_int, vp]
     L.pf_feed_jpeg.argtypes = [vp, C.c_char_p, C.c_size_t, dp]
+    L.pf_debug_jpeg_huffman.argtypes = [vp, C.POINTER(C.c_longlong)]; L.pf_debug_jpeg_huffman.restype = None
     L.pf_feed_jpeg_batch.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), dp, C.c_int, ip]
     L.pf_num_levels.argtypes = [vp]
     L.pf_pyramid_type.argtypes = [vp]
@@ -249,6 +250,14 @@ def decode_jpeg_device(data, dev_ptr, rows, cols, stream=None):
     L = lib(); b = bytes(data)
     if not L.pf_jpeg_decode_device(b, len(b), dev_ptr, rows, cols, stream):
         raise ValueError("decode_jpeg_device: %s" % L.pf_last_error().decode())
+
+
+def jpeg_huffman_counts(map2d=None):
+    """(frames whose Huffman pass ran on the GPU, frames that fell back to the host after trying, rounds of the most recent GPU pass) of a map's
+    decoder, or of decode_jpeg_device's when map2d is None"""
+    out = (C.c_longlong * 3)()
+    lib().pf_debug_jpeg_huffman(map2d._h if map2d is not None else None, out)
+    return tuple(out)
 
 
 def tile_owner(opt, ix, iy):

@@ -21,6 +21,10 @@ struct pf_map {
     ~pf_map() { if (impl.ok() && impl.use_device()) impl.sync(); }          // the decoder's buffers go before the engine: nothing may still read them
 };
 
+// pf_jpeg_decode_device's decoder: process-wide, never torn down (the runtime may be gone at exit)
+static std::mutex g_jpeg_mu;
+static pf::JpegDevice* shared_jpeg() { static pf::JpegDevice* d = new pf::JpegDevice(); return d; }
+
 extern "C" {
 
 void pf_default_options(pf_options* o)
@@ -107,9 +111,16 @@ int pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, 
 { return rows > 0 && cols > 0 && pf::jpeg_decode_bgr(data, len, bgr, rows, cols, (size_t)cols * 3); }
 int pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream)
 {
-    static std::mutex mu; static pf::JpegDevice* dec = new pf::JpegDevice();     // process-wide, never torn down (the runtime may be gone at exit)
-    std::lock_guard<std::mutex> l(mu);
-    return rows > 0 && cols > 0 && dec->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
+    std::lock_guard<std::mutex> l(g_jpeg_mu);
+    return rows > 0 && cols > 0 && shared_jpeg()->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
+}
+void pf_debug_jpeg_huffman(pf_map* m, long long out[3])
+{
+    if (!out) return;
+    long a = 0, b = 0; int r = 0;
+    if (m) m->jpeg.huffman_counts(&a, &b, &r);
+    else { std::lock_guard<std::mutex> l(g_jpeg_mu); shared_jpeg()->huffman_counts(&a, &b, &r); }
+    out[0] = a; out[1] = b; out[2] = r;
 }
 // one staged frame (JpegDevice slot i) into the map: the frame's slot in HBM is filled by the decoder's upload + kernels on the map's stream
 static int feed_staged_jpeg(pf_map* m, int i, const double pose[7])

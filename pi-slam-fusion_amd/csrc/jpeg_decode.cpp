@@ -7,6 +7,7 @@
 // integral sampling ratio.  Not supported (false + pf_last_error): arithmetic coding, lossless, 12-bit, 4 components.
 // Host code only; nothing here touches the device.
 #include "jpeg_decode.hpp"
+#include "jpeg_huff_par.hpp"
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -200,6 +201,7 @@ struct Decoder {
     Huff dc[4], ac[4];
     std::string err;
     int16_t* store = nullptr; size_t store_cap = 0;      // optional caller storage for the coefficients of all components
+    bool plan_only = false; size_t sos_s = 0, sos_e = 0;    // jpeg_scan_plan: stop at the first scan header, before any storage is touched
 
     Decoder(const uint8_t* data, size_t len) : d(data), n(len) {}
     size_t coef_count() const
@@ -264,6 +266,7 @@ struct Decoder {
                     k.w = (W * k.h + hmax - 1) / hmax; k.ht = (H * k.v + vmax - 1) / vmax;
                 }
                 if (stop_at_frame) return true;
+                if (plan_only) continue;
                 if (store && store_cap < coef_count()) return fail("coefficient storage too small");
                 size_t off = 0;
                 for (int c = 0; c < ncomp; c++) {
@@ -308,6 +311,7 @@ struct Decoder {
                 if (e - s >= 12 && !std::memcmp(d + s, "Adobe", 5)) { adobe = true; adobe_transform = d[s + 11]; }
             } else if (m == 0xDA) {
                 if (!have_frame) return fail("scan before the frame header");
+                if (plan_only) { sos_s = s; sos_e = e; return true; }
                 if (!scan(s, e)) return false;
             }
         }
@@ -617,6 +621,74 @@ bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t*
     for (int c = 0; c < dec.ncomp; c++)
         if (!dec.qt_set[dec.comp[c].tq]) { set_error("jpeg: frame uses a quantisation table that was not defined"); return false; }
     describe(dec, f);
+    return true;
+}
+
+// What the parallel Huffman pass (jpeg_huff_par.hpp) needs of a stream it is able to take -- sequential, ONE scan holding every component in
+// frame order, no restart interval, nothing but entropy-coded bytes up to EOI: the frame, the scan's tables and block layout, and the scan's
+// bytes with the stuffing removed (into `bits`, 16 zero bytes after them).  false (quietly: it is a question, not an error) otherwise.
+bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes)
+{
+    if (!data || !bits) return false;
+    Decoder dec(data, len);
+    dec.plan_only = true;
+    if (!dec.read_headers(false) || !dec.sos_e || dec.progressive || dec.restart) return false;
+    const uint8_t* d = data; const size_t s = dec.sos_s, e = dec.sos_e;
+    const int ns = d[s];
+    if (ns != dec.ncomp || e - s < (size_t)(4 + 2 * ns)) return false;
+    std::memset(&P, 0, sizeof(P));
+    int bpm = 0;
+    for (int i = 0; i < ns; i++) {
+        Comp& k = dec.comp[i];
+        if (d[s + 1 + 2 * i] != k.id) return false;                                  // frame order
+        const int td = (d[s + 2 + 2 * i] >> 4) & 3, ta = d[s + 2 + 2 * i] & 3;
+        if (!dec.dc[td].set || !dec.ac[ta].set || !dec.qt_set[k.tq]) return false;
+        const int bh = ns > 1 ? k.h : 1, bv = ns > 1 ? k.v : 1;
+        if (ns == 1 && (k.bw != (k.w + 7) / 8 || k.bh != (k.ht + 7) / 8)) return false;      // a lone component's scan skips padding blocks
+        for (int v = 0; v < bv; v++)
+            for (int h = 0; h < bh; h++) {
+                if (bpm >= 10) return false;
+                P.comp_of[bpm] = i; P.hh[bpm] = h; P.vv[bpm] = v; P.dct[bpm] = td; P.act[bpm] = ta;
+                bpm++;
+            }
+        P.ch[i] = bh; P.cv[i] = bv; P.cbw[i] = k.bw; P.cblocks[i] = k.bw * k.bh;
+    }
+    for (int t = 0; t < 4; t++)
+        for (int w = 0; w < 2; w++) {
+            const Huff& h = w ? dec.ac[t] : dec.dc[t];
+            if (!h.set) continue;
+            HuffParTable& o = P.tab[4 * w + t];
+            static_assert(kParLook == kLookBits, "one table shape for both decoders");
+            std::memcpy(o.look, h.look, sizeof(o.look)); std::memcpy(o.maxcode, h.maxcode, sizeof(o.maxcode));
+            std::memcpy(o.valoff, h.valoff, sizeof(o.valoff)); std::memcpy(o.vals, h.vals, sizeof(o.vals));
+        }
+    describe(dec, f);
+    for (int i = 0; i < ns; i++) P.coef_off[i] = (uint32_t)f.c[i].coef_off;
+    if (f.coef_count >= (1ull << 31)) return false;
+    P.bpm = bpm; P.mcux = dec.mcux; P.mcuy = dec.mcuy; P.ncomp = ns;
+    P.total_blocks = ns > 1 ? dec.mcux * dec.mcuy * bpm : dec.comp[0].bw * dec.comp[0].bh;
+    if (ns == 1) { P.mcux = dec.comp[0].bw; P.mcuy = dec.comp[0].bh; }                 // one block per "MCU", row-major over the component
+    // the scan's bytes without the stuffing, up to the marker that ends it -- which has to be EOI
+    const uint8_t* p = d + e; const uint8_t* end = d + len;
+    size_t o = 0;
+    for (;;) {
+        const uint8_t* ff = (const uint8_t*)std::memchr(p, 0xFF, (size_t)(end - p));
+        if (!ff) return false;                                                        // no marker after the scan
+        const size_t run = (size_t)(ff - p);
+        if (o + run + 1 + 16 > cap) return false;
+        std::memcpy(bits + o, p, run); o += run;
+        p = ff + 1;
+        while (p < end && *p == 0xFF) p++;                                            // fill bytes
+        if (p >= end) return false;
+        if (*p == 0) { bits[o++] = 0xFF; p++; continue; }
+        if (*p != 0xD9) return false;                                                 // RSTn, DNL, another scan's tables: the serial pass's business
+        break;
+    }
+    if (o == 0 || o * 8 >= (1ull << 31)) return false;
+    std::memset(bits + o, 0, 16);                                                     // a symbol that starts on the last bits may be read to its end
+    *nbytes = o;
+    P.nbits = (uint32_t)(o * 8);
+    P.nsub = (int32_t)((P.nbits + kSubBits - 1) / kSubBits);
     return true;
 }
 

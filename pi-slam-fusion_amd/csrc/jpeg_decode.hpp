@@ -30,6 +30,9 @@ struct JpegFrame {
 bool jpeg_frame_info(const uint8_t* data, size_t len, JpegFrame& f);
 // coefficients of every block, natural order, 64 per block, blocks row-major per component, components one after another in `store`
 bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t* store, size_t store_cap);
+struct HuffParPlan;            // jpeg_huff_par.hpp
+// the plan of a parallel Huffman pass over the stream's one scan, and the scan's bytes with the stuffing removed; false when the stream is not of that kind
+bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes);
 bool read_file_bytes(const char* filename, std::vector<uint8_t>& out);
 bool read_image_file(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols);
 }  // namespace pf

@@ -7,9 +7,12 @@
 // Both kernels are HBM-bound byte work: 2 B of coefficients in and 1 B out per sample; 1.5 B of planes in and 3 B out per pixel
 // (4:2:0).  A 4000 x 3000 4:2:0 frame: 54 MB + 54 MB.
 #include "jpeg_device.hpp"
+#include "jpeg_huff_par.hpp"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstddef>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -30,6 +33,7 @@ struct JpegDevFrame {
 static_assert(offsetof(JpegDevFrame, c[0].q) % 16 == 0 && sizeof(JpegDevComp) % 16 == 0, "quantiser rows are loaded 16 bytes at a time");
 static_assert(sizeof(JpegDevFrame) <= 1024, "the header travels in the first KiB of the coefficient buffer");
 constexpr size_t kHeaderBytes = 1024;
+constexpr size_t kPlanBytes = (sizeof(HuffParPlan) + 255) & ~(size_t)255;          // the parallel Huffman pass's plan, then the scan's bytes
 
 namespace {
 
@@ -243,6 +247,85 @@ __global__ __launch_bounds__(256) void k_jpeg_colour8(const JpegDevFrame* __rest
     for (int i = 0; i < 6; i++) d4[i] = o[4 * i] | (o[4 * i + 1] << 8) | (o[4 * i + 2] << 16) | (o[4 * i + 3] << 24);
 }
 
+// ---- the Huffman pass in parallel (jpeg_huff_par.hpp): one thread per subsequence of kSubBits bits
+struct HuffParResult { uint32_t g_end, p, ck, pad_; };
+
+// round 0: every subsequence from its own first bit as if a block began there; round r: from the end state its predecessor recorded in
+// round r - 1.  changed[r] is raised when a subsequence's result differs from the previous round's: a round that raises nothing is the fixed point.
+__global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
+                                                     HuffParState* __restrict__ out, uint32_t* __restrict__ nblk, uint32_t* __restrict__ changed, int round)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= P->nsub) return;
+    HuffParState s0 = { 0u, 0u };
+    if (round == 0) s0.p = (uint32_t)i * (uint32_t)kSubBits;
+    else if (i > 0) s0 = in[i - 1];
+    HuffParState e; uint32_t n;
+    huff_par_sub(*P, P->tab, words, i, s0, e, n);
+    if (round > 0) {
+        const HuffParState o = in[i];
+        if (o.p != e.p || o.ck != e.ck || nblk[i] != n) changed[round] = 1u;
+    }
+    out[i] = e; nblk[i] = n;
+}
+
+// exclusive sum of the blocks completed per subsequence: the index of the block each subsequence starts in.  One workgroup.
+__global__ __launch_bounds__(1024) void k_huff_prefix(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, uint32_t* __restrict__ first)
+{
+    __shared__ uint32_t part[1024];
+    const int S = P->nsub, t = (int)threadIdx.x, per = (S + 1023) / 1024;
+    const int a = t * per < S ? t * per : S, b = a + per < S ? a + per : S;
+    uint32_t sum = 0;
+    for (int j = a; j < b; j++) sum += nblk[j];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = t ? part[t - 1] : 0u;
+    for (int j = a; j < b; j++) { first[j] = run; run += nblk[j]; }
+}
+
+// the write pass: coefficients into the dense array (zeroed before; DC values as differences), the last subsequence's end for the host to check
+__global__ __launch_bounds__(256) void k_huff_write(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ st,
+                                                     const uint32_t* __restrict__ first, int16_t* __restrict__ coef, HuffParResult* __restrict__ res)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (i >= P->nsub) return;
+    HuffParState s0 = { 0u, 0u };
+    if (i > 0) s0 = st[i - 1];
+    HuffParState e; uint32_t ge;
+    huff_par_write(*P, P->tab, words, i, s0, first[i], coef, e, ge);
+    if (i == P->nsub - 1) { res->g_end = ge; res->p = e.p; res->ck = e.ck; }
+}
+
+// DC differences -> DC values: a running sum per component in scan order (jdhuff.c last_dc_val).  One workgroup per component.
+__global__ __launch_bounds__(1024) void k_huff_dc(const HuffParPlan* __restrict__ P, int16_t* __restrict__ coef)
+{
+    __shared__ int part[1024];
+    const int comp = (int)blockIdx.x, N = P->cblocks[comp], t = (int)threadIdx.x, per = (N + 1023) / 1024;
+    const int a = t * per < N ? t * per : N, b = a + per < N ? a + per : N;
+    int sum = 0;
+    for (int j = a; j < b; j++) sum += coef[huff_par_comp_block(*P, comp, (uint32_t)j)];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t ? part[t - 1] : 0;
+    for (int j = a; j < b; j++) {
+        const uint32_t at = huff_par_comp_block(*P, comp, (uint32_t)j);
+        run += coef[at];
+        coef[at] = (int16_t)run;
+    }
+}
+
 bool hip_ok(hipError_t e, const char* what)
 {
     if (e == hipSuccess) return true;
@@ -260,6 +343,8 @@ JpegDevice::~JpegDevice()
     }
     if (dev_) (void)hipFree(dev_);
     if (planes_) (void)hipFree(planes_);
+    if (huff_) (void)hipFree(huff_);
+    if (res_host_) (void)hipHostFree(res_host_);
 }
 
 // Host side of a frame, step 1 (calling thread): the geometry, and a pinned buffer that the previous upload out of it has left
@@ -272,7 +357,9 @@ bool JpegDevice::prepare(int i, const uint8_t* data, size_t len, int rows, int c
     if (!jpeg_frame_info(data, len, s.f)) return false;
     if (rows > 0 && (s.f.rows != rows || s.f.cols != cols)) { set_error("jpeg device: the output buffer does not have the image's size"); return false; }
     if (s.f.coef_count >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
-    const size_t need = kHeaderBytes + s.f.coef_count * sizeof(int16_t);
+    size_t need = kHeaderBytes + s.f.coef_count * sizeof(int16_t);
+    need = std::max(need, kHeaderBytes + kPlanBytes + len + 64);          // the parallel pass's layout: header, plan, the scan's bytes
+    s.data = data; s.len = len; s.par = false;
     if (s.done && s.used && !hip_ok(hipEventSynchronize((hipEvent_t)s.done), "wait for the staging buffer")) return false;
     s.used = false;
     if (s.cap < need) {
@@ -289,12 +376,69 @@ bool JpegDevice::prepare(int i, const uint8_t* data, size_t len, int rows, int c
 bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
 {
     Slot& s = slot_[i];
+    static const bool host_huffman = getenv("PF_JPEG_HOST_HUFFMAN") != nullptr;          // A/B and tests: the serial pass on the host for every stream
+    if (!host_huffman) {
+        // a stream the parallel pass takes: its scan's bytes (stuffing removed) and the plan go to the GPU, nothing else happens here
+        HuffParPlan* plan = (HuffParPlan*)((char*)s.host + kHeaderBytes);
+        uint8_t* bits = (uint8_t*)s.host + kHeaderBytes + kPlanBytes;
+        if (jpeg_scan_plan(data, len, s.f, *plan, bits, s.cap - kHeaderBytes - kPlanBytes, &s.par_bytes)) { s.par = true; s.staged = true; return true; }
+    }
     s.staged = jpeg_entropy_decode(data, len, s.f, (int16_t*)((char*)s.host + kHeaderBytes), s.f.coef_count);
     if (!s.staged) s.err = last_error();
     return s.staged;
 }
 
-// ... step 3 (calling thread): upload and the two kernels on `stream`
+// The Huffman pass of slot i on the GPU (jpeg_huff_par.hpp): coefficients into dev_ behind the header.  false: the rounds did not settle or
+// the write pass did not end on the frame's last block -- the caller falls back to the serial pass.
+bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Slot& s = slot_[i];
+    const HuffParPlan* hp = (const HuffParPlan*)((char*)s.host + kHeaderBytes);
+    const size_t S = (size_t)hp->nsub, wbytes = (s.par_bytes + 16 + 255) & ~(size_t)255;
+    const size_t o_st0 = kPlanBytes + wbytes, o_st1 = o_st0 + S * 8, o_nblk = o_st1 + S * 8, o_first = o_nblk + S * 4,
+                 o_flags = (o_first + S * 4 + 255) & ~(size_t)255, total = o_flags + kMaxRounds * 4 + 256;
+    if (huff_cap_ < total) {
+        if (huff_) (void)hipFree(huff_);
+        huff_ = nullptr; huff_cap_ = 0;
+        if (!hip_ok(hipMalloc(&huff_, total + total / 4), "Huffman work buffer")) return false;
+        huff_cap_ = total + total / 4;
+    }
+    if (!res_host_ && !hip_ok(hipHostMalloc(&res_host_, kMaxRounds * 4 + 256, hipHostMallocDefault), "result buffer")) return false;
+    char* hb = (char*)huff_;
+    const HuffParPlan* P = (const HuffParPlan*)hb;
+    const uint32_t* words = (const uint32_t*)(hb + kPlanBytes);
+    HuffParState* stt[2] = { (HuffParState*)(hb + o_st0), (HuffParState*)(hb + o_st1) };
+    uint32_t* nblk = (uint32_t*)(hb + o_nblk); uint32_t* first = (uint32_t*)(hb + o_first);
+    uint32_t* changed = (uint32_t*)(hb + o_flags); HuffParResult* res = (HuffParResult*)(hb + o_flags + kMaxRounds * 4);
+    if (!hip_ok(hipMemcpyAsync(hb, (char*)s.host + kHeaderBytes, kPlanBytes + s.par_bytes + 16, hipMemcpyHostToDevice, st), "scan upload")) return false;
+    if (!hip_ok(hipMemsetAsync(changed, 0, kMaxRounds * 4 + 256, st), "flags")) return false;
+    if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
+    const dim3 grid((unsigned)((S + 255) / 256));
+    hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], nblk, changed, 0);
+    int cur = 0, round = 0; bool settled = S == 1;
+    while (!settled && round + kRoundsPerCheck < kMaxRounds) {
+        for (int r = 0; r < kRoundsPerCheck; r++) {
+            round++;
+            hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], nblk, changed, round);
+            cur ^= 1;
+        }
+        if (!hip_ok(hipMemcpyAsync(res_host_, changed, kMaxRounds * 4, hipMemcpyDeviceToHost, st), "flags read-back")) return false;
+        if (!hip_ok(hipStreamSynchronize(st), "Huffman rounds")) return false;
+        settled = ((const uint32_t*)res_host_)[round] == 0;
+    }
+    last_rounds_ = round;
+    if (!settled) return false;
+    hipLaunchKernelGGL(k_huff_prefix, dim3(1), dim3(1024), 0, st, P, (const uint32_t*)nblk, first);
+    hipLaunchKernelGGL(k_huff_write, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, (int16_t*)((char*)dev_ + kHeaderBytes), res);
+    hipLaunchKernelGGL(k_huff_dc, dim3((unsigned)hp->ncomp), dim3(1024), 0, st, P, (int16_t*)((char*)dev_ + kHeaderBytes));
+    if (!hip_ok(hipMemcpyAsync(res_host_, res, sizeof(HuffParResult), hipMemcpyDeviceToHost, st), "result read-back")) return false;
+    if (!hip_ok(hipStreamSynchronize(st), "Huffman write pass")) return false;
+    const HuffParResult* r = (const HuffParResult*)res_host_;
+    return r->g_end == (uint32_t)hp->total_blocks && r->ck == 0 && hp->nbits - r->p < 8;
+}
+
+// ... step 3 (calling thread): the coefficients get to the GPU -- decoded there, or uploaded -- and the two kernels follow on `stream`
 bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -304,7 +448,7 @@ bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
     s.staged = false;
     const JpegFrame& f = s.f;
     const int rows = f.rows, cols = f.cols;
-    const size_t need = kHeaderBytes + f.coef_count * sizeof(int16_t);
+    const size_t coef_bytes = f.coef_count * sizeof(int16_t), need = kHeaderBytes + coef_bytes;
     JpegDevFrame h;
     std::memset(&h, 0, sizeof(h));
     h.rows = f.rows; h.cols = f.cols; h.ncomp = f.ncomp; h.ycc = f.ycc ? 1 : 0;
@@ -321,7 +465,6 @@ bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
     }
     for (int c = f.ncomp; c < 4; c++) h.block_first[c] = blocks;
     if (plane_bytes >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
-    std::memcpy(s.host, &h, sizeof(h));
 
     if (dev_cap_ < need) {
         if (dev_) (void)hipFree(dev_);
@@ -335,7 +478,19 @@ bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
         if (!hip_ok(hipMalloc(&planes_, plane_bytes), "plane buffer")) return false;
         planes_cap_ = plane_bytes;
     }
-    if (!hip_ok(hipMemcpyAsync(dev_, s.host, need, hipMemcpyHostToDevice, st), "coefficient upload")) return false;
+    bool on_device = false;
+    if (s.par) {
+        on_device = huffman_on_device(i, stream, coef_bytes);
+        par_frames_ += on_device ? 1 : 0;
+        if (!on_device) {                                  // the serial pass after all (the stream and its length were kept by prepare)
+            fallback_frames_++;
+            if (!hip_ok(hipStreamSynchronize(st), "before the fallback")) return false;
+            JpegFrame f2;
+            if (!jpeg_entropy_decode(s.data, s.len, f2, (int16_t*)((char*)s.host + kHeaderBytes), f.coef_count)) return false;
+        }
+    }
+    std::memcpy(s.host, &h, sizeof(h));
+    if (!hip_ok(hipMemcpyAsync(dev_, s.host, on_device ? kHeaderBytes : need, hipMemcpyHostToDevice, st), "coefficient upload")) return false;
     if (!hip_ok(hipEventRecord((hipEvent_t)s.done, st), "event record")) return false;
     s.used = true;
     const JpegDevFrame* dh = (const JpegDevFrame*)dev_;
@@ -350,7 +505,7 @@ bool JpegDevice::submit(int i, uint8_t* dev_bgr, void* stream)
     else if (camera && hc[1].ve == 1) hipLaunchKernelGGL((k_jpeg_colour8<2, 1>), g8, dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
     else if (camera) hipLaunchKernelGGL((k_jpeg_colour8<2, 2>), g8, dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
     else hipLaunchKernelGGL(k_jpeg_colour, dim3((unsigned)((cols + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, dh, (const uint8_t*)planes_, dev_bgr);
-    last_ = { f.coef_count * sizeof(int16_t), plane_bytes, (size_t)rows * cols * 3 };
+    last_ = { coef_bytes, plane_bytes, (size_t)rows * cols * 3 };
     return hip_ok(hipGetLastError(), "kernel launch");
 }
 

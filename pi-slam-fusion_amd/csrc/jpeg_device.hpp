@@ -24,8 +24,16 @@ public:
     bool submit(int i, uint8_t* dev_bgr, void* stream);
     void staged_size(int i, int* rows, int* cols) const { *rows = slot_[i].f.rows; *cols = slot_[i].f.cols; }
     Bytes last_bytes() const { return last_; }          // of the most recent frame: what the two kernels read and wrote
+    // frames whose Huffman pass ran on the GPU / fell back to the host after trying, and the rounds the most recent one took
+    void  huffman_counts(long* on_device, long* fell_back, int* rounds) const { *on_device = par_frames_; *fell_back = fallback_frames_; *rounds = last_rounds_; }
 private:
-    struct Slot { void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false, staged = false; JpegFrame f; std::string err; };
+    struct Slot {
+        void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false, staged = false; JpegFrame f; std::string err;
+        const uint8_t* data = nullptr; size_t len = 0;        // the stream (the caller's, valid until submit): a fallback decodes it again
+        bool par = false; size_t par_bytes = 0;              // staged for the Huffman pass on the GPU: the scan's bytes, stuffing removed
+    };
+    enum { kMaxRounds = 256, kRoundsPerCheck = 16 };
+    bool huffman_on_device(int i, void* stream, size_t coef_bytes);
     bool prepare(int i, const uint8_t* data, size_t len, int rows, int cols);
     bool entropy(int i, const uint8_t* data, size_t len);
     Slot   slot_[kSlots];
@@ -33,6 +41,9 @@ private:
     void*  dev_ = nullptr;    size_t dev_cap_ = 0;
     void*  planes_ = nullptr; size_t planes_cap_ = 0;
     Bytes  last_ = { 0, 0, 0 };
+    void*  huff_ = nullptr;   size_t huff_cap_ = 0;          // plan, scan bytes, subsequence states and counts of the parallel Huffman pass
+    void*  res_host_ = nullptr;
+    int    last_rounds_ = 0; long par_frames_ = 0, fallback_frames_ = 0;
 };
 
 }  // namespace pf

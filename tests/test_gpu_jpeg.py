@@ -2,6 +2,7 @@
 the host's Huffman pass) against the host decoder (csrc/jpeg_decode.cpp) and against libjpeg-turbo's pixels: byte-equal.  Then
 pf_feed_jpeg -- feed(cv::imread(imgfile), pose), backup/map2dfusion.cpp:129-135 -- against the oracle fed libjpeg-turbo's pixels."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -11,6 +12,8 @@ from helpers import jitter_poses, workloads
 from test_jpeg import picture, vectors
 
 pytestmark = pytest.mark.gpu
+TESTS_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT_DIR = os.path.dirname(TESTS_DIR)
 
 
 def on_device(pf, stream_bytes):
@@ -152,3 +155,42 @@ def test_feed_jpeg_batch_builds_the_same_mosaic_as_one_by_one(pf, thread):
         mos.append(m.save_to_memory()[0])
         m.close()
     assert np.array_equal(mos[0], mos[1])
+
+
+def test_huffman_pass_runs_on_the_gpu_for_one_scan_streams_and_on_the_host_for_the_rest(pf):
+    """the streams a camera writes (sequential, one scan, no restart interval) are entropy-decoded on the GPU too (csrc/jpeg_huff_par.hpp);
+    everything else keeps the host's serial pass -- the pixels are the host decoder's either way"""
+    Image = pytest.importorskip("PIL.Image")
+    a = picture(600, 800, 42)
+    for kw, on_gpu in [({"quality": 85, "subsampling": 2}, True), ({"quality": 100, "subsampling": 0}, True), ({"quality": 50, "subsampling": 1, "optimize": True}, True),
+                       ({"quality": 85, "subsampling": 2, "progressive": True}, False), ({"quality": 85, "subsampling": 2, "restart_marker_blocks": 7}, False)]:
+        b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", **kw); s = b.getvalue()
+        g0, f0, _ = pf.jpeg_huffman_counts()
+        assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s)), kw
+        g1, f1, rounds = pf.jpeg_huffman_counts()
+        assert (g1 - g0, f1 - f0) == ((1, 0) if on_gpu else (0, 0)), (kw, g1 - g0, f1 - f0, rounds)
+    b = io.BytesIO(); Image.fromarray(a).convert("L").save(b, "JPEG", quality=70); s = b.getvalue()
+    g0, f0, _ = pf.jpeg_huffman_counts()
+    assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s))
+    assert pf.jpeg_huffman_counts()[0] == g0 + 1
+    # a stream whose entropy-coded bytes are damaged but whose headers are whole: tried on the GPU, found not to end on the last block,
+    # decoded by the serial pass after all -- with the serial pass's pixels
+    b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", quality=85, subsampling=2); s = bytearray(b.getvalue())
+    mid = len(s) // 2
+    s[mid:mid + 3] = bytes([0x12, 0x34, 0x56]) if bytes(s[mid:mid + 3]) != bytes([0x12, 0x34, 0x56]) else bytes([0x65, 0x43, 0x21])
+    g0, f0, _ = pf.jpeg_huffman_counts()
+    assert np.array_equal(on_device(pf, bytes(s)), pf.decode_jpeg(bytes(s)))
+    g1, f1, _ = pf.jpeg_huffman_counts()
+    assert (g1 - g0) + (f1 - f0) == 1
+
+
+def test_host_huffman_switch(pf, tmp_path):
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\nfrom conftest import load_package\nfrom test_jpeg import vectors\n"
+            "pf = load_package(); _, s, rgb = vectors()[0]\n"
+            "out = torch.zeros(rgb.shape, dtype=torch.uint8, device='cuda'); pf.decode_jpeg_device(s, out.data_ptr(), rgb.shape[0], rgb.shape[1]); torch.cuda.synchronize()\n"
+            "assert np.array_equal(out.cpu().numpy()[:, :, ::-1], rgb); print('counts', pf.jpeg_huffman_counts())\n") % (ROOT_DIR, TESTS_DIR)
+    for env_extra, want in (({}, "counts (1, 0,"), ({"PF_JPEG_HOST_HUFFMAN": "1"}, "counts (0, 0,")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0 and want in r.stdout.decode(), r.stdout.decode()[-2000:]
