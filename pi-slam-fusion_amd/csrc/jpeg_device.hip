@@ -250,18 +250,38 @@ __global__ __launch_bounds__(256) void k_jpeg_colour8(const JpegDevFrame* __rest
 // ---- the Huffman pass in parallel (jpeg_huff_par.hpp): one thread per subsequence of kSubBits bits
 struct HuffParResult { uint32_t g_end, p, ck, pad_; };
 
+// A workgroup's 256 subsequences are contiguous in the stream: their words (plus what a symbol starting on the window's last bit may
+// still read) and the code tables are staged in LDS once -- a symbol costs two or three dependent look-ups, and from L2 those were the whole
+// of a round's 72 us (10 us from LDS).
+constexpr int kSubWords = kSubBits / 32;
+constexpr int kStageWords = 256 * kSubWords + 4;
+struct HuffLds { HuffParTable tab[8]; uint32_t words[kStageWords]; };
+
+__device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, HuffLds& L, uint32_t first_sub)
+{
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(P->tab);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(L.tab);
+    for (unsigned j = threadIdx.x; j < sizeof(L.tab) / 4; j += 256) dst[j] = src[j];
+    const uint32_t w0 = first_sub * (uint32_t)kSubWords, navail = ((P->nbits >> 3) + 16 + 3) / 4;      // the scan's bytes and the 16 zero bytes behind them
+    for (unsigned j = threadIdx.x; j < (unsigned)kStageWords; j += 256) { const uint32_t w = w0 + j; L.words[j] = w < navail ? words[w] : 0u; }
+    __syncthreads();
+}
+
 // round 0: every subsequence from its own first bit as if a block began there; round r: from the end state its predecessor recorded in
 // round r - 1.  changed[r] is raised when a subsequence's result differs from the previous round's: a round that raises nothing is the fixed point.
 __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
                                                      HuffParState* __restrict__ out, uint32_t* __restrict__ nblk, uint32_t* __restrict__ changed, int round)
 {
-    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    __shared__ HuffLds L;
+    const uint32_t first = blockIdx.x * 256u;
+    huff_stage(P, words, L, first);
+    const int i = (int)(first + threadIdx.x);
     if (i >= P->nsub) return;
     HuffParState s0 = { 0u, 0u };
     if (round == 0) s0.p = (uint32_t)i * (uint32_t)kSubBits;
     else if (i > 0) s0 = in[i - 1];
     HuffParState e; uint32_t n;
-    huff_par_sub(*P, P->tab, words, i, s0, e, n);
+    huff_par_sub(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, n);
     if (round > 0) {
         const HuffParState o = in[i];
         if (o.p != e.p || o.ck != e.ck || nblk[i] != n) changed[round] = 1u;
@@ -269,60 +289,90 @@ __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restric
     out[i] = e; nblk[i] = n;
 }
 
-// exclusive sum of the blocks completed per subsequence: the index of the block each subsequence starts in.  One workgroup.
-__global__ __launch_bounds__(1024) void k_huff_prefix(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, uint32_t* __restrict__ first)
-{
-    __shared__ uint32_t part[1024];
-    const int S = P->nsub, t = (int)threadIdx.x, per = (S + 1023) / 1024;
-    const int a = t * per < S ? t * per : S, b = a + per < S ? a + per : S;
-    uint32_t sum = 0;
-    for (int j = a; j < b; j++) sum += nblk[j];
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const uint32_t v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = t ? part[t - 1] : 0u;
-    for (int j = a; j < b; j++) { first[j] = run; run += nblk[j]; }
-}
-
 // the write pass: coefficients into the dense array (zeroed before; DC values as differences), the last subsequence's end for the host to check
 __global__ __launch_bounds__(256) void k_huff_write(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ st,
-                                                     const uint32_t* __restrict__ first, int16_t* __restrict__ coef, HuffParResult* __restrict__ res)
+                                                     const uint32_t* __restrict__ first_block, int16_t* __restrict__ coef, HuffParResult* __restrict__ res)
 {
-    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    __shared__ HuffLds L;
+    const uint32_t first = blockIdx.x * 256u;
+    huff_stage(P, words, L, first);
+    const int i = (int)(first + threadIdx.x);
     if (i >= P->nsub) return;
     HuffParState s0 = { 0u, 0u };
     if (i > 0) s0 = st[i - 1];
     HuffParState e; uint32_t ge;
-    huff_par_write(*P, P->tab, words, i, s0, first[i], coef, e, ge);
+    huff_par_write(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, first_block[i], coef, e, ge);
     if (i == P->nsub - 1) { res->g_end = ge; res->p = e.p; res->ck = e.ck; }
 }
 
-// DC differences -> DC values: a running sum per component in scan order (jdhuff.c last_dc_val).  One workgroup per component.
-__global__ __launch_bounds__(1024) void k_huff_dc(const HuffParPlan* __restrict__ P, int16_t* __restrict__ coef)
+// ---- running sums over many workgroups: MODE 0 = blocks completed per subsequence -> first block of each subsequence (exclusive);
+// MODE 1 = DC differences of a component in scan order -> DC values (inclusive, jdhuff.c last_dc_val).  Three small launches each:
+// per-workgroup totals of 1024 elements, an exclusive scan of the totals, the elements again with their workgroup's offset.
+constexpr int kScanPer = 4, kScanTile = 256 * kScanPer;
+template <int MODE>
+__device__ inline int scan_elem(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, const int16_t* __restrict__ coef, int comp, int j)
+{
+    return MODE == 0 ? (int)nblk[j] : (int)coef[huff_par_comp_block(*P, comp, (uint32_t)j)];
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_totals(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, const int16_t* __restrict__ coef,
+                                                      int* __restrict__ totals, int stride)
+{
+    __shared__ int red[256];
+    const int comp = (int)blockIdx.y, N = MODE == 0 ? P->nsub : P->cblocks[comp], t = (int)threadIdx.x;
+    const int j0 = ((int)blockIdx.x * 256 + t) * kScanPer;
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < kScanPer; e++) if (j0 + e < N) sum += scan_elem<MODE>(P, nblk, coef, comp, j0 + e);
+    red[t] = sum;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if (t < d) red[t] += red[t + d]; __syncthreads(); }
+    if (t == 0) totals[comp * stride + (int)blockIdx.x] = red[0];
+}
+// exclusive scan of each row of `totals` in place; one workgroup per row
+__global__ __launch_bounds__(1024) void k_scan_top(int* __restrict__ totals, int stride, int n0, int n1, int n2)
 {
     __shared__ int part[1024];
-    const int comp = (int)blockIdx.x, N = P->cblocks[comp], t = (int)threadIdx.x, per = (N + 1023) / 1024;
-    const int a = t * per < N ? t * per : N, b = a + per < N ? a + per : N;
+    const int row = (int)blockIdx.x, n = row == 0 ? n0 : row == 1 ? n1 : n2, t = (int)threadIdx.x, per = (n + 1023) / 1024;
+    int* v = totals + row * stride;
+    const int a = t * per < n ? t * per : n, b = a + per < n ? a + per : n;
     int sum = 0;
-    for (int j = a; j < b; j++) sum += coef[huff_par_comp_block(*P, comp, (uint32_t)j)];
+    for (int j = a; j < b; j++) sum += v[j];
     part[t] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        const int v = t >= d ? part[t - d] : 0;
+        const int x = t >= d ? part[t - d] : 0;
         __syncthreads();
-        part[t] += v;
+        part[t] += x;
         __syncthreads();
     }
     int run = t ? part[t - 1] : 0;
-    for (int j = a; j < b; j++) {
-        const uint32_t at = huff_par_comp_block(*P, comp, (uint32_t)j);
-        run += coef[at];
-        coef[at] = (int16_t)run;
+    for (int j = a; j < b; j++) { const int x = v[j]; v[j] = run; run += x; }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void k_scan_apply(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, int16_t* __restrict__ coef,
+                                                     uint32_t* __restrict__ first_block, const int* __restrict__ totals, int stride)
+{
+    __shared__ int part[256];
+    const int comp = (int)blockIdx.y, N = MODE == 0 ? P->nsub : P->cblocks[comp], t = (int)threadIdx.x;
+    const int j0 = ((int)blockIdx.x * 256 + t) * kScanPer;
+    int v[kScanPer], sum = 0;
+#pragma unroll
+    for (int e = 0; e < kScanPer; e++) { v[e] = j0 + e < N ? scan_elem<MODE>(P, nblk, coef, comp, j0 + e) : 0; sum += v[e]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int x = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int run = totals[comp * stride + (int)blockIdx.x] + (t ? part[t - 1] : 0);
+#pragma unroll
+    for (int e = 0; e < kScanPer; e++) {
+        if (j0 + e >= N) break;
+        if (MODE == 0) { first_block[j0 + e] = (uint32_t)run; run += v[e]; }
+        else { run += v[e]; coef[huff_par_comp_block(*P, comp, (uint32_t)(j0 + e))] = (int16_t)run; }
     }
 }
 
@@ -397,7 +447,11 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     const HuffParPlan* hp = (const HuffParPlan*)((char*)s.host + kHeaderBytes);
     const size_t S = (size_t)hp->nsub, wbytes = (s.par_bytes + 16 + 255) & ~(size_t)255;
     const size_t o_st0 = kPlanBytes + wbytes, o_st1 = o_st0 + S * 8, o_nblk = o_st1 + S * 8, o_first = o_nblk + S * 4,
-                 o_flags = (o_first + S * 4 + 255) & ~(size_t)255, total = o_flags + kMaxRounds * 4 + 256;
+                 o_flags = (o_first + S * 4 + 255) & ~(size_t)255, o_tot = o_flags + kMaxRounds * 4 + 256;
+    int cmax = 0;
+    for (int c = 0; c < hp->ncomp; c++) cmax = std::max(cmax, hp->cblocks[c]);
+    const int stride = (int)std::max((S + kScanTile - 1) / kScanTile, (size_t)(cmax + kScanTile - 1) / kScanTile) + 1;
+    const size_t total = o_tot + (size_t)stride * 3 * 4;
     if (huff_cap_ < total) {
         if (huff_) (void)hipFree(huff_);
         huff_ = nullptr; huff_cap_ = 0;
@@ -411,6 +465,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     HuffParState* stt[2] = { (HuffParState*)(hb + o_st0), (HuffParState*)(hb + o_st1) };
     uint32_t* nblk = (uint32_t*)(hb + o_nblk); uint32_t* first = (uint32_t*)(hb + o_first);
     uint32_t* changed = (uint32_t*)(hb + o_flags); HuffParResult* res = (HuffParResult*)(hb + o_flags + kMaxRounds * 4);
+    int* totals = (int*)(hb + o_tot);
     if (!hip_ok(hipMemcpyAsync(hb, (char*)s.host + kHeaderBytes, kPlanBytes + s.par_bytes + 16, hipMemcpyHostToDevice, st), "scan upload")) return false;
     if (!hip_ok(hipMemsetAsync(changed, 0, kMaxRounds * 4 + 256, st), "flags")) return false;
     if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
@@ -429,9 +484,17 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     }
     last_rounds_ = round;
     if (!settled) return false;
-    hipLaunchKernelGGL(k_huff_prefix, dim3(1), dim3(1024), 0, st, P, (const uint32_t*)nblk, first);
-    hipLaunchKernelGGL(k_huff_write, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, (int16_t*)((char*)dev_ + kHeaderBytes), res);
-    hipLaunchKernelGGL(k_huff_dc, dim3((unsigned)hp->ncomp), dim3(1024), 0, st, P, (int16_t*)((char*)dev_ + kHeaderBytes));
+    int16_t* dcoef = (int16_t*)((char*)dev_ + kHeaderBytes);
+    const int tiles_s = (int)((S + kScanTile - 1) / kScanTile);
+    hipLaunchKernelGGL((k_scan_totals<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, totals, stride, tiles_s, 0, 0);
+    hipLaunchKernelGGL((k_scan_apply<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride);
+    hipLaunchKernelGGL(k_huff_write, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, dcoef, res);
+    int tc[3] = { 0, 0, 0 }, tmax = 0;
+    for (int c = 0; c < hp->ncomp; c++) { tc[c] = (hp->cblocks[c] + kScanTile - 1) / kScanTile; tmax = std::max(tmax, tc[c]); }
+    hipLaunchKernelGGL((k_scan_totals<1>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);
+    hipLaunchKernelGGL(k_scan_top, dim3((unsigned)hp->ncomp), dim3(1024), 0, st, totals, stride, tc[0], tc[1], tc[2]);
+    hipLaunchKernelGGL((k_scan_apply<1>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride);
     if (!hip_ok(hipMemcpyAsync(res_host_, res, sizeof(HuffParResult), hipMemcpyDeviceToHost, st), "result read-back")) return false;
     if (!hip_ok(hipStreamSynchronize(st), "Huffman write pass")) return false;
     const HuffParResult* r = (const HuffParResult*)res_host_;

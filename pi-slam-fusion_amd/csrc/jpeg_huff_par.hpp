@@ -49,11 +49,21 @@ struct HuffParPlan {
 
 struct HuffParState { uint32_t p; uint32_t ck; };                // bit position; c | k << 8
 
+// what a symbol's decode needs of the plan, in registers: the table of every block of the MCU, four bits each
+struct HuffParCtl { uint64_t dc_pack, ac_pack; int bpm; };
+PF_HD HuffParCtl huff_par_ctl(const HuffParPlan& P)
+{
+    HuffParCtl c = { 0, 0, P.bpm };
+    for (int i = 0; i < 10; i++) { c.dc_pack |= (uint64_t)(P.dct[i] & 15) << (4 * i); c.ac_pack |= (uint64_t)((4 + P.act[i]) & 15) << (4 * i); }
+    return c;
+}
+
 PF_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 
 // 16 bits of the stream at bit position p (words: the stream as aligned little-endian loads of its bytes; 16 zero bytes follow the data)
 PF_HD uint32_t peek16(const uint32_t* __restrict__ words, uint32_t p)
 {
+    // (p is relative to words[0]: the callers subtract the first bit of the window they staged)
     const uint32_t w = p >> 5;
     const uint64_t v = ((uint64_t)bswap32(words[w]) << 32) | bswap32(words[w + 1]);
     return (uint32_t)((v << (p & 31)) >> 48);
@@ -69,11 +79,11 @@ PF_HD int zigzag_of(int k)
 
 // One symbol (jdhuff.c decode_mcu_slow; jpeg_decode.cpp block_sequential).  In: the state.  Out: the state after the symbol, `wpos` = natural
 // index the symbol's value belongs at in the current block (-1: none), `done`: the block ended with this symbol.
-PF_HD void huff_par_step(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words,
+PF_HD void huff_par_step(const HuffParCtl& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, uint32_t bit0,
                          uint32_t& p, int& c, int& k, int& wpos, int& value, bool& done)
 {
-    const HuffParTable& t = tabs[k == 0 ? P.dct[c] : 4 + P.act[c]];
-    const uint32_t pre = peek16(words, p);
+    const HuffParTable& t = tabs[(int)(((k == 0 ? P.dc_pack : P.ac_pack) >> (4 * c)) & 15)];
+    const uint32_t pre = peek16(words, p - bit0);
     const uint32_t e = t.look[pre >> (16 - kParLook)];
     int len, sym;
     if (e) { len = (int)(e >> 8); sym = (int)(e & 255); }
@@ -87,13 +97,13 @@ PF_HD void huff_par_step(const HuffParPlan& P, const HuffParTable* __restrict__ 
     wpos = -1; value = 0; done = false;
     if (k == 0) {                                    // DC difference
         const int s = sym & 15;
-        if (s) { const int x = (int)(peek16(words, p) >> (16 - s)); p += (uint32_t)s; value = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x; }
+        if (s) { const int x = (int)(peek16(words, p - bit0) >> (16 - s)); p += (uint32_t)s; value = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x; }
         wpos = 0; k = 1;
     } else {
         const int r = sym >> 4, s = sym & 15;
         if (s) {
             k += r;
-            const int x = (int)(peek16(words, p) >> (16 - s)); p += (uint32_t)s;
+            const int x = (int)(peek16(words, p - bit0) >> (16 - s)); p += (uint32_t)s;
             value = x < (1 << (s - 1)) ? x - (1 << s) + 1 : x;
             wpos = zigzag_of(k);
             k++;
@@ -105,16 +115,17 @@ PF_HD void huff_par_step(const HuffParPlan& P, const HuffParTable* __restrict__ 
 }
 
 // Subsequence i decoded from `start` to its end: the state there and the blocks completed on the way
-PF_HD void huff_par_sub(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, int i,
+PF_HD void huff_par_sub(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, uint32_t bit0, int i,
                         HuffParState start, HuffParState& end, uint32_t& nblk)
 {
     const uint64_t lim64 = (uint64_t)(i + 1) * kSubBits;
     const uint32_t limit = lim64 < P.nbits ? (uint32_t)lim64 : P.nbits;
     uint32_t p = start.p; int c = (int)(start.ck & 255), k = (int)(start.ck >> 8);
     uint32_t n = 0;
+    const HuffParCtl ctl = huff_par_ctl(P);
     while (p < limit) {
         int wpos, value; bool done;
-        huff_par_step(P, tabs, words, p, c, k, wpos, value, done);
+        huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
         n += done ? 1u : 0u;
     }
     end.p = p; end.ck = (uint32_t)c | ((uint32_t)k << 8);
@@ -132,7 +143,7 @@ PF_HD uint32_t huff_par_block_base(const HuffParPlan& P, uint32_t mcu, int c)
 
 // The write pass of subsequence i: from the exact start state, in the block with index `g` (blocks completed before the subsequence).
 // Returns false when the decode leaves the frame (more blocks than the frame holds): the stream is not one this decoder takes.
-PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, int i,
+PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, uint32_t bit0, int i,
                           HuffParState start, uint32_t g, int16_t* __restrict__ coef, HuffParState& end, uint32_t& g_end)
 {
     const uint64_t lim64 = (uint64_t)(i + 1) * kSubBits;
@@ -140,11 +151,10 @@ PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__
     uint32_t p = start.p; int c = (int)(start.ck & 255), k = (int)(start.ck >> 8);
     const uint32_t total = (uint32_t)P.total_blocks;
     uint32_t base = g < total ? huff_par_block_base(P, g / (uint32_t)P.bpm, c) : 0u;
+    const HuffParCtl ctl = huff_par_ctl(P);
     while (p < limit && g < total) {
         int wpos, value; bool done;
-        const int c0 = c;
-        huff_par_step(P, tabs, words, p, c, k, wpos, value, done);
-        (void)c0;
+        huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
         if (wpos >= 0 && value != 0) coef[base + (uint32_t)wpos] = (int16_t)value;
         if (done) {
             g++;

@@ -24,14 +24,14 @@ int main(int argc, char** argv)
         const int S = P.nsub;
         std::vector<pf::HuffParState> st[2] = { std::vector<pf::HuffParState>(S), std::vector<pf::HuffParState>(S) };
         std::vector<uint32_t> nblk(S);
-        for (int i = 0; i < S; i++) { pf::HuffParState s0 = { (uint32_t)i * pf::kSubBits, 0 }; pf::huff_par_sub(P, P.tab, words.data(), i, s0, st[0][i], nblk[i]); }
+        for (int i = 0; i < S; i++) { pf::HuffParState s0 = { (uint32_t)i * pf::kSubBits, 0 }; pf::huff_par_sub(P, P.tab, words.data(), 0u, i, s0, st[0][i], nblk[i]); }
         int rounds = 0, cur = 0;
         for (;;) {
             bool changed = false;
             st[cur ^ 1][0] = st[cur][0];
             for (int i = 1; i < S; i++) {
                 pf::HuffParState e; uint32_t n;
-                pf::huff_par_sub(P, P.tab, words.data(), i, st[cur][i - 1], e, n);
+                pf::huff_par_sub(P, P.tab, words.data(), 0u, i, st[cur][i - 1], e, n);
                 if (e.p != st[cur][i].p || e.ck != st[cur][i].ck || n != nblk[i]) changed = true;
                 st[cur ^ 1][i] = e; nblk[i] = n;
             }
@@ -43,7 +43,7 @@ int main(int argc, char** argv)
         for (int i = 0; i < S; i++) {
             pf::HuffParState s0 = i ? st[cur][i - 1] : pf::HuffParState{ 0, 0 };
             pf::HuffParState e; uint32_t ge;
-            ok = pf::huff_par_write(P, P.tab, words.data(), i, s0, g, coef.data(), e, ge) && ok;
+            ok = pf::huff_par_write(P, P.tab, words.data(), 0u, i, s0, g, coef.data(), e, ge) && ok;
             g += nblk[i]; last = e; g_last = ge;
         }
         const bool ends = g_last == (uint32_t)P.total_blocks && last.ck == 0 && P.nbits - last.p < 8;
