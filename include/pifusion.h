@@ -118,9 +118,10 @@ int     pf_image_info(const char* filename, int* rows, int* cols);
 int     pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols);
 int     pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components);
 int     pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols);
-/* The same decode with its back end on the GPU: markers and Huffman on the calling thread, then the coefficients cross PCIe
- * once and two kernels do libjpeg's dequantise + ISLOW IDCT, fancy upsampling and colour conversion (csrc/jpeg_device.hip),
- * byte-equal to pf_jpeg_decode_bgr.  dev_bgr: rows*cols*3 bytes of device memory, complete in the order of `hip_stream`
+/* The same decode on the GPU (csrc/jpeg_device.hip), byte-equal to pf_jpeg_decode_bgr: the calling thread parses the markers;
+ * sequential one-scan streams without restart intervals are Huffman-decoded on the GPU too (a self-synchronising parallel pass,
+ * csrc/jpeg_huff_par.hpp), the others on the calling thread; kernels do libjpeg's dequantise + ISLOW IDCT, fancy upsampling and
+ * colour conversion.  dev_bgr: rows*cols*3 bytes of device memory, complete in the order of `hip_stream`
  * (a hipStream_t, NULL = the default stream); the call returns when the work is queued.                               */
 int     pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream);
 /* Diagnostics: out = { frames whose Huffman pass ran on the GPU, frames that fell back to the host's serial pass after trying,

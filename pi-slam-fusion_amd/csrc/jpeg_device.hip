@@ -471,16 +471,22 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
     const dim3 grid((unsigned)((S + 255) / 256));
     hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], nblk, changed, 0);
+    // Rounds are launched in groups and the flags read back after each group (a read-back costs a stream synchronisation, a round past the
+    // fixed point costs a launch that changes nothing).  Consecutive keyframes of a camera settle after about the same number of rounds: the
+    // first group is the previous frame's count plus two, the following groups four rounds each.
     int cur = 0, round = 0; bool settled = S == 1;
-    while (!settled && round + kRoundsPerCheck < kMaxRounds) {
-        for (int r = 0; r < kRoundsPerCheck; r++) {
+    int group = std::min(std::max(settle_hint_ + 2, 4), (int)kMaxRounds - 1);
+    while (!settled && round + group < kMaxRounds) {
+        for (int r = 0; r < group; r++) {
             round++;
             hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], nblk, changed, round);
             cur ^= 1;
         }
         if (!hip_ok(hipMemcpyAsync(res_host_, changed, kMaxRounds * 4, hipMemcpyDeviceToHost, st), "flags read-back")) return false;
         if (!hip_ok(hipStreamSynchronize(st), "Huffman rounds")) return false;
-        settled = ((const uint32_t*)res_host_)[round] == 0;
+        const uint32_t* fl = (const uint32_t*)res_host_;
+        for (int r = 1; r <= round && !settled; r++) if (fl[r] == 0) { settled = true; settle_hint_ = r; }
+        group = 4;
     }
     last_rounds_ = round;
     if (!settled) return false;

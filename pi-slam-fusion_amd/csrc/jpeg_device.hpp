@@ -32,7 +32,7 @@ private:
         const uint8_t* data = nullptr; size_t len = 0;        // the stream (the caller's, valid until submit): a fallback decodes it again
         bool par = false; size_t par_bytes = 0;              // staged for the Huffman pass on the GPU: the scan's bytes, stuffing removed
     };
-    enum { kMaxRounds = 256, kRoundsPerCheck = 16 };
+    enum { kMaxRounds = 256 };
     bool huffman_on_device(int i, void* stream, size_t coef_bytes);
     bool prepare(int i, const uint8_t* data, size_t len, int rows, int cols);
     bool entropy(int i, const uint8_t* data, size_t len);
@@ -43,7 +43,7 @@ private:
     Bytes  last_ = { 0, 0, 0 };
     void*  huff_ = nullptr;   size_t huff_cap_ = 0;          // plan, scan bytes, subsequence states and counts of the parallel Huffman pass
     void*  res_host_ = nullptr;
-    int    last_rounds_ = 0; long par_frames_ = 0, fallback_frames_ = 0;
+    int    last_rounds_ = 0, settle_hint_ = 14; long par_frames_ = 0, fallback_frames_ = 0;
 };
 
 }  // namespace pf

@@ -24,7 +24,19 @@ int main(int argc, char** argv)
         const int S = P.nsub;
         std::vector<pf::HuffParState> st[2] = { std::vector<pf::HuffParState>(S), std::vector<pf::HuffParState>(S) };
         std::vector<uint32_t> nblk(S);
-        for (int i = 0; i < S; i++) { pf::HuffParState s0 = { (uint32_t)i * pf::kSubBits, 0 }; pf::huff_par_sub(P, P.tab, words.data(), 0u, i, s0, st[0][i], nblk[i]); }
+        // round 0 with every block of the MCU as the assumed one (the GPU: one thread per subsequence and phase), then the phases linked
+        // from subsequence to subsequence: c at the end of i - 1 picks the candidate of i
+        const int bpm = P.bpm;
+        std::vector<pf::HuffParState> cand((size_t)S * bpm); std::vector<uint32_t> cn((size_t)S * bpm);
+        for (int i = 0; i < S; i++)
+            for (int c0 = 0; c0 < bpm; c0++) {
+                pf::HuffParState s0 = { (uint32_t)i * pf::kSubBits, (uint32_t)c0 };
+                pf::huff_par_sub(P, P.tab, words.data(), 0u, i, s0, cand[(size_t)i * bpm + c0], cn[(size_t)i * bpm + c0]);
+            }
+        {
+            int c = 0;
+            for (int i = 0; i < S; i++) { st[0][i] = cand[(size_t)i * bpm + c]; nblk[i] = cn[(size_t)i * bpm + c]; c = (int)(st[0][i].ck & 255); }
+        }
         int rounds = 0, cur = 0;
         for (;;) {
             bool changed = false;
