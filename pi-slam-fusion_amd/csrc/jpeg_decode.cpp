@@ -644,7 +644,6 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
         const int td = (d[s + 2 + 2 * i] >> 4) & 3, ta = d[s + 2 + 2 * i] & 3;
         if (!dec.dc[td].set || !dec.ac[ta].set || !dec.qt_set[k.tq]) return false;
         const int bh = ns > 1 ? k.h : 1, bv = ns > 1 ? k.v : 1;
-        if (ns == 1 && (k.bw != (k.w + 7) / 8 || k.bh != (k.ht + 7) / 8)) return false;      // a lone component's scan skips padding blocks
         for (int v = 0; v < bv; v++)
             for (int h = 0; h < bh; h++) {
                 if (bpm >= 10) return false;
@@ -666,8 +665,14 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
     for (int i = 0; i < ns; i++) P.coef_off[i] = (uint32_t)f.c[i].coef_off;
     if (f.coef_count >= (1ull << 31)) return false;
     P.bpm = bpm; P.mcux = dec.mcux; P.mcuy = dec.mcuy; P.ncomp = ns;
-    P.total_blocks = ns > 1 ? dec.mcux * dec.mcuy * bpm : dec.comp[0].bw * dec.comp[0].bh;
-    if (ns == 1) { P.mcux = dec.comp[0].bw; P.mcuy = dec.comp[0].bh; }                 // one block per "MCU", row-major over the component
+    if (ns == 1) {
+        // a lone component's scan: one block per "MCU", row-major over the blocks that hold real samples (the padding blocks the storage
+        // may have to the right and below -- sampling factors above 1 -- are not in the stream)
+        const Comp& k = dec.comp[0];
+        P.mcux = (k.w + 7) / 8; P.mcuy = (k.ht + 7) / 8;
+        P.ch[0] = P.cv[0] = 1; P.cblocks[0] = P.mcux * P.mcuy;
+    }
+    P.total_blocks = P.mcux * P.mcuy * bpm;
     // the scan's bytes without the stuffing, up to the marker that ends it -- which has to be EOI
     const uint8_t* p = d + e; const uint8_t* end = d + len;
     size_t o = 0;

@@ -427,7 +427,8 @@ bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
 {
     Slot& s = slot_[i];
     static const bool host_huffman = getenv("PF_JPEG_HOST_HUFFMAN") != nullptr;          // A/B and tests: the serial pass on the host for every stream
-    if (!host_huffman) {
+    if (!host_huffman && skip_par_ > 0) skip_par_--;            // a recent stream of this consumer did not settle: its neighbours will not either
+    else if (!host_huffman) {
         // a stream the parallel pass takes: its scan's bytes (stuffing removed) and the plan go to the GPU, nothing else happens here
         HuffParPlan* plan = (HuffParPlan*)((char*)s.host + kHeaderBytes);
         uint8_t* bits = (uint8_t*)s.host + kHeaderBytes + kPlanBytes;
@@ -489,7 +490,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
         group = 4;
     }
     last_rounds_ = round;
-    if (!settled) return false;
+    if (!settled) { skip_par_ = 15; return false; }          // (streams of quality 99 noise do this: ~250 rounds are 11 ms thrown away)
     int16_t* dcoef = (int16_t*)((char*)dev_ + kHeaderBytes);
     const int tiles_s = (int)((S + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL((k_scan_totals<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);
