@@ -6,8 +6,6 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
-#include <atomic>
-#include <thread>
 #include <vector>
 #include <mutex>
 #include <new>

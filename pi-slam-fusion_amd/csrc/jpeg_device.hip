@@ -1,11 +1,14 @@
-// jpeg_device.hip -- the back end of cv::imread's JPEG leg (backup/map2dfusion.cpp:129-132) on the GPU: the host does the
-// part that is serial (markers + Huffman, jpeg_decode.cpp's entropy stage, a quarter to a third of a host decode), the
-// coefficients cross PCIe once (the size of the frame they become), and two kernels do what libjpeg does after the entropy
-// decoder -- dequantise + ISLOW IDCT per 8x8 block (jidctint.c) into component planes, then fancy upsampling (jdsample.c) and
-// YCbCr -> BGR (jdcolor.c) per pixel -- writing the BGR8 keyframe where the level kernel reads it.  Integer arithmetic
-// throughout: byte-equal to jpeg_decode.cpp and therefore to libjpeg-turbo (tests/test_gpu_jpeg.py).
-// Both kernels are HBM-bound byte work: 2 B of coefficients in and 1 B out per sample; 1.5 B of planes in and 3 B out per pixel
-// (4:2:0).  A 4000 x 3000 4:2:0 frame: 54 MB + 54 MB.
+// jpeg_device.hip -- cv::imread's JPEG leg (backup/map2dfusion.cpp:129-132) on the GPU, byte-equal to jpeg_decode.cpp and therefore to
+// libjpeg-turbo (tests/test_gpu_jpeg.py); integer arithmetic throughout.
+//   Huffman pass   for the streams cameras write (sequential, one scan, no restart interval) the host parses the headers and strips the byte
+//                  stuffing; the scan's bytes cross PCIe and are decoded one thread per 512-bit subsequence in rounds until a round changes
+//                  nothing (jpeg_huff_par.hpp; k_huff_round, k_scan_*, k_huff_write).  Any other stream, and any stream whose write pass
+//                  does not end exactly on the frame's last block, is entropy-decoded on the host (jpeg_decode.cpp) and its coefficients
+//                  uploaded (2 B per sample: the size of the frame they become).
+//   back end       dequantise + ISLOW IDCT per 8x8 block (jidctint.c) into component planes (k_jpeg_idct), then fancy upsampling
+//                  (jdsample.c) and YCbCr -> BGR (jdcolor.c) per pixel (k_jpeg_colour8 / k_jpeg_colour), writing the BGR8 keyframe where
+//                  the level kernel reads it.  HBM-bound byte work: 2 B of coefficients in and 1 B out per sample; 1.5 B of planes in and
+//                  3 B out per pixel (4:2:0) -- 54 MB + 54 MB for a 4000 x 3000 frame.
 #include "jpeg_device.hpp"
 #include "jpeg_huff_par.hpp"
 #include <hip/hip_runtime.h>
