@@ -232,6 +232,10 @@ void     pf_dist_destroy(pf_dist* d);
  * ranks; each rank then renders its tiles (a rank that holds none of the canvas only advances its grid).  thread=0 maps.
  * Returns 1 (accepted), 0 (rejected as Map2D::feed would: oblique view ...), -1 (failure, on every rank alike).          */
 int      pf_dist_feed(pf_dist* d, const pf_image* img, const double pose[7], int root);
+/* The same with the keyframe as the bytes of its .jpg file (pf_feed_jpeg across ranks): only the root reads `data`; every rank
+ * makes the call with the same pose and the frame's size (rows, cols: the camera's).  The root decodes on its GPU straight into
+ * the slot the exchange sends from.                                                                                       */
+int      pf_dist_feed_jpeg(pf_dist* d, const uint8_t* data, size_t len, int rows, int cols, const double pose[7], int root);
 /* draw() across ranks: every rank blends ITS changed tiles (at most cap) with the edge strips of neighbours that live on
  * other ranks and clears their Ischanged flags.  One pack launch, one grouped exchange, one batched blend per call.
  * Returns the number of tiles written to xy / bgr (cap tiles of 256x256x3 each), -1 on failure.                     */

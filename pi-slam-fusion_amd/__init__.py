@@ -120,6 +120,7 @@ def lib():
     L.pf_dist_destroy.argtypes = [vp]; L.pf_dist_destroy.restype = None
     L.pf_dist_blend_changed.argtypes = [vp, ip, vp, C.c_int]
     L.pf_dist_feed.argtypes = [vp, C.POINTER(Image), dp, C.c_int]
+    L.pf_dist_feed_jpeg.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int, dp, C.c_int]
     L.pf_dist_save.argtypes = [vp, C.c_char_p]
     L.pf_dist_save_to_memory.argtypes = [vp, vp, ip, ip, ip, ip]
     L.pf_dist_last_stats.argtypes = [vp, C.POINTER(DistStats)]

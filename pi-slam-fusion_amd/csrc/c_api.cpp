@@ -255,23 +255,41 @@ int pf_tile_export(pf_map* m, int ix, int iy, void* dev_out) { return m && dev_o
 int pf_tile_import(pf_map* m, int ix, int iy, const void* dev_in) { return m && dev_in && m->impl.tile_import(ix, iy, dev_in); }
 
 // --- seam exchange (dist.cpp)
-struct pf_dist { pf::DistMap impl; pf_dist(pf::FusionMap* m, pf::Transport* t) : impl(m, t) {} };
+struct pf_dist { pf::DistMap impl; pf_map* owner; pf_dist(pf_map* m, pf::Transport* t) : impl(&m->impl, t), owner(m) {} };
 int pf_dist_unique_id(void* out128) { return out128 && pf::rccl_unique_id(out128); }
 pf_dist* pf_dist_init_rccl(pf_map* m, const void* id128, int rank, int nranks)
 {
     if (!m || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
     pf::Transport* t = pf::make_rccl_transport(id128, rank, nranks, m->impl.device());
-    return t ? new (std::nothrow) pf_dist(&m->impl, t) : nullptr;
+    return t ? new (std::nothrow) pf_dist(m, t) : nullptr;
 }
 pf_dist* pf_dist_init_host(pf_map* m, int rank, int nranks, pf_exchange_fn fn, void* user)
 {
     if (!m || !fn || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
     pf::Transport* t = pf::make_host_transport(rank, nranks, fn, user);
-    return t ? new (std::nothrow) pf_dist(&m->impl, t) : nullptr;
+    return t ? new (std::nothrow) pf_dist(m, t) : nullptr;
 }
 void pf_dist_destroy(pf_dist* d) { delete d; }
 int pf_dist_blend_changed(pf_dist* d, int* xy, uint8_t* bgr, int cap) { return (d && xy && bgr && cap >= 0) ? d->impl.blend_changed(xy, bgr, cap) : -1; }
 int pf_dist_feed(pf_dist* d, const pf_image* img, const double pose[7], int root) { return (d && img && pose) ? d->impl.feed(img, pose, root) : -1; }
+int pf_dist_feed_jpeg(pf_dist* d, const uint8_t* data, size_t len, int rows, int cols, const double pose[7], int root)
+{
+    if (!d || !pose) return -1;
+    pf_image img = { rows, cols, PF_8UC3, nullptr, 0 };
+    if (d->impl.rank() != root) return d->impl.feed(&img, pose, root);
+    // the root: markers + (where the stream needs it) Huffman here, the rest queued on the map's stream into the staged slot
+    pf_map* m = d->owner;
+    unsigned char ok = 0; int i = -1;
+    if (data && m->impl.ok() && m->impl.use_device()) i = m->jpeg.stage_one(data, len, &ok);
+    const FusionMap::FrameProducer fill = [m, i, ok, rows, cols](void* dev, hipStream_t st) {
+        int r = 0, c = 0;
+        if (i < 0 || !ok) { if (i >= 0) m->jpeg.submit(i, nullptr, nullptr); else pf::set_error("pf_dist_feed_jpeg: the root has no stream"); return false; }
+        m->jpeg.staged_size(i, &r, &c);
+        if (r != rows || c != cols) { pf::set_error("pf_dist_feed_jpeg: the stream does not have the size announced to the ranks"); return false; }
+        return m->jpeg.submit(i, (uint8_t*)dev, (void*)st);
+    };
+    return d->impl.feed(&img, pose, root, &fill);
+}
 int pf_dist_save(pf_dist* d, const char* filename) { return d && filename && d->impl.save(filename); }
 int pf_dist_save_to_memory(pf_dist* d, uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0)
 { return d && rows && cols && tx0 && ty0 && d->impl.save_to_memory(bgr, rows, cols, tx0, ty0); }

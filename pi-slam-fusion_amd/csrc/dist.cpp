@@ -466,7 +466,9 @@ bool DistMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* 
 // alone, which ranks own a tile of the frame's canvas; the root copies the pixels to its GPU once and sends them -- one
 // grouped point-to-point exchange -- to exactly those ranks; every rank then renders its tiles (or, holding none of the
 // canvas, only advances its grid).  No rank is fed through its own PCIe link except the root.
-int DistMap::feed(const pf_image* img, const double pose7[7], int root)
+int DistMap::rank() const { return t_->rank; }
+
+int DistMap::feed(const pf_image* img, const double pose7[7], int root, const FusionMap::FrameProducer* produce)
 {
     stats_ = {};
     if (!img || !m_->use_device()) return -1;
@@ -477,12 +479,16 @@ int DistMap::feed(const pf_image* img, const double pose7[7], int root)
     if (m_->reject_mismatched_frame(img)) return 0;
     std::vector<unsigned char> needs;
     bool ok_here = m_->frame_needs(pose7, needs) && (int)needs.size() == n;
-    if (ok_here && me == root && !img->data) { set_error("pf_dist_feed: the root has no pixels"); ok_here = false; }
+    if (ok_here && me == root && !img->data && !produce) { set_error("pf_dist_feed: the root has no pixels"); ok_here = false; }
     bool anyone = false;
     for (int p = 0; ok_here && p < n; p++) anyone = anyone || (needs[p] && p != root);
     int slot = -1; void* dev = nullptr; size_t bytes = 0;
     const bool i_take = ok_here && needs[me], i_send = ok_here && me == root && anyone;
-    if (i_take || i_send) { slot = m_->stage_frame(img, me == root, &dev, &bytes); ok_here = slot >= 0; }
+    if (i_take || i_send) {
+        slot = m_->stage_frame(img, me == root && !produce, &dev, &bytes);
+        ok_here = slot >= 0;
+        if (ok_here && me == root && produce) ok_here = (*produce)(dev, m_->stream());          // stream order puts it ahead of the exchange and the render
+    }
     if (!agree(ok_here)) { m_->release_staged(slot); return -1; }
     if (n > 1 && anyone) {
         std::vector<const void*> s(n, nullptr); std::vector<void*> r(n, nullptr);

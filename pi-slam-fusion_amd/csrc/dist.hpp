@@ -37,7 +37,10 @@ public:
     int  blend_changed(int* xy, uint8_t* bgr, int cap);        // tiles blended on this rank, -1 on failure
     bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0);
     bool save(const char* filename);
-    int  feed(const pf_image* img, const double pose7[7], int root);   // 1 rendered / accepted, 0 rejected, -1 failure
+    // 1 rendered / accepted, 0 rejected, -1 failure.  `produce` (root only, img->data == nullptr): the root's pixels are written into its
+    // staged slot by the caller's own work on the map's stream (pf_dist_feed_jpeg: the decoder) instead of being uploaded
+    int  feed(const pf_image* img, const double pose7[7], int root, const FusionMap::FrameProducer* produce = nullptr);
+    int  rank() const;
     const pf_dist_stats& stats() const { return stats_; }
     const Transport* transport() const { return t_; }
     void set_verify(bool on) { verify_ = on; }

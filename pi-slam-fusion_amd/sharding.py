@@ -102,6 +102,17 @@ class DistMap:
             raise RuntimeError("pf_dist_feed failed: %s" % pf.lib().pf_last_error().decode())
         return bool(rc)
 
+    def feed_jpeg(self, data, pose, shape, root=0):
+        """pf_dist_feed_jpeg: the keyframe as the bytes of its .jpg file, read on `root` only (the others pass None); every rank gives the
+        frame's (rows, cols).  The root decodes on its GPU into the slot the exchange sends from."""
+        pf = _pkg()
+        p = np.ascontiguousarray(pose, dtype=np.float64).reshape(-1)
+        b = bytes(data) if data is not None else None
+        rc = pf.lib().pf_dist_feed_jpeg(self._h, b, len(b) if b is not None else 0, int(shape[0]), int(shape[1]), p.ctypes.data_as(C.POINTER(C.c_double)), root)
+        if rc < 0:
+            raise RuntimeError("pf_dist_feed_jpeg failed: %s" % pf.lib().pf_last_error().decode())
+        return bool(rc)
+
     def blend_changed(self, cap=None):
         """draw() across ranks: this rank's changed tiles, blended with remote neighbour strips -> (coords, pixels)"""
         pf = _pkg()

@@ -308,6 +308,66 @@ def test_dist_feed_from_one_rank(pf, orc, world, force_float, root):
         d.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root", [(3, 1), (4, 0)])
+def test_dist_feed_jpeg_from_one_rank(pf, orc, world, root):
+    """pf_dist_feed_jpeg: the keyframes are .jpg streams on the host of ONE rank, which decodes them on its GPU straight into the slot the
+    exchange sends from; shards' tiles = the oracle fed libjpeg-turbo's pixels (backup/map2dfusion.cpp:129-135 across ranks)"""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 24)          # Pillow's progressive pass wants the whole stream in one buffer
+    sh = importlib.import_module("pi_slam_fusion_amd.sharding")
+    wl = workloads()
+    cam, poses, frames = workload(wl)
+    streams, decoded = [], []
+    for k, f in enumerate(frames):
+        b = io.BytesIO(); Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])).save(b, "JPEG", quality=88, subsampling=[2, 0, 1][k % 3], progressive=(k % 4 == 3))
+        streams.append(b.getvalue())
+        decoded.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(b.getvalue())).convert("RGB"))[:, :, ::-1]))
+    o = orc.OracleMap(force_float=0, scale=2.0)
+    assert o.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    for f, p in zip(decoded, poses):
+        assert o.feed(f, p)
+    maps = [pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=0, scale=2.0, shard_rank=r, shard_count=world, shard_block=2) for r in range(world)]
+    for m in maps:
+        assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:2])
+    rv = Rendezvous(world)
+    dms = [sh.DistMap(m, r, world, backend="host", exchange=rv.fn(r)) for r, m in enumerate(maps)]
+    for d in dms:
+        d.set_verify(True)
+    shape = frames[0].shape
+
+    def rank_main(r):
+        for s, p in zip(streams, poses):
+            assert dms[r].feed_jpeg(s if r == root else None, p, shape, root=root) is True
+        # a broken stream on the root fails on every rank together, and the ranks carry on
+        try:
+            dms[r].feed_jpeg(b"\xff\xd8junk" if r == root else None, poses[0], shape, root=root)
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised
+        assert dms[r].feed_jpeg(streams[0] if r == root else None, poses[0], shape, root=root) is True
+        assert maps[r].sync()
+        return 0
+    assert o.feed(decoded[0], poses[0])
+    collective(world, rv, rank_main)
+    from helpers import map_digest
+    want, got = map_digest(o), {}
+    for r, m in enumerate(maps):
+        d = map_digest(m)
+        assert not (set(d) & set(got))
+        got.update(d)
+    assert got == want
+    if root < world:
+        assert pf.jpeg_huffman_counts(maps[root])[0] >= len(streams) - 3          # the sequential streams: Huffman pass on the root's GPU
+    for d in dms:
+        d.close()
+    for m in maps:
+        m.close()
+
+
 def test_dist_caps_and_empty_ranks(pf, orc):
     """a rank may take fewer tiles per call than it has changed (cap), and a rank may hold no tile at all: the providers
     plan with the requester's cap, and the calls repeat until nothing is left"""
