@@ -111,7 +111,8 @@ int     pf_save(pf_map* m, const char* filename);
 int     pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols);
 /* Input side of the file driver: the reference reads each keyframe with cv::imread(imgfile), backup/map2dfusion.cpp:129-132
  * (8-bit BGR, EXIF orientation ignored as OpenCV 2.4.9 does).  JPEG (baseline, extended and progressive Huffman; grey or
- * YCbCr/RGB; libjpeg's default ISLOW IDCT, fancy upsampling and colour tables, byte-equal to libjpeg-turbo) and binary PPM.
+ * YCbCr/RGB; libjpeg's default ISLOW IDCT, fancy upsampling and colour tables, byte-equal to libjpeg-turbo), PNG (non-interlaced;
+ * grey replicated, palette looked up, alpha dropped, 16-bit samples cut to 8: IMREAD_COLOR's conversion) and binary PPM.
  * pf_image_info fills rows/cols; pf_read_image decodes into rows*cols*3 bytes.  pf_jpeg_* take the stream from memory.
  * Host code; no device needed.  0 + pf_last_error() on anything unsupported or malformed.                              */
 int     pf_image_info(const char* filename, int* rows, int* cols);

@@ -7,7 +7,7 @@
 //
 // Header-only over include/pifusion/Map2D.h.  The reference decodes frames with cv::imread; here
 // <name>.jpg goes through the library's own JPEG decoder (pf_read_image: libjpeg's default decode byte
-// for byte, csrc/jpeg_decode.cpp), <name>.ppm (binary P6) is read when there is no .jpg, and a decoder
+// for byte, csrc/jpeg_decode.cpp), <name>.png or <name>.ppm (binary P6) is read when there is no .jpg, and a decoder
 // hook (`DroneMapDataset::decoder`) takes over the .jpg when set -- cv::imread plugs in there.
 #ifndef PIFUSION_TESTSYSTEM_H
 #define PIFUSION_TESTSYSTEM_H
@@ -151,7 +151,7 @@ public:
         if (encoded) encoded->clear();
         if (encoded && !decoder && read_bytes(base + ".jpg", *encoded)) { /* decoded by the map */ }
         else if (!(decoder ? decoder(base + ".jpg", frame.first) : read_native(base + ".jpg", frame.first)) &&
-                 !read_ppm_bgr(base + ".ppm", frame.first)) return false;
+                 !read_native(base + ".png", frame.first) && !read_ppm_bgr(base + ".ppm", frame.first)) return false;
         frame.second = pi::SE3d(p[0], p[1], p[2], p[3], p[4], p[5], p[6]);      // SE3 stream order x y z qx qy qz qw (SE3.h:112-117)
         return true;
     }

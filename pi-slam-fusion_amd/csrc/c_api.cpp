@@ -92,6 +92,7 @@ int pf_image_info(const char* filename, int* rows, int* cols)
     std::vector<uint8_t> b;
     if (!pf::read_file_bytes(filename, b)) return 0;
     if (b.size() >= 2 && b[0] == 0xFF && b[1] == 0xD8) return pf::jpeg_info(b.data(), b.size(), rows, cols, nullptr);
+    if (b.size() >= 8 && b[0] == 0x89 && b[1] == 'P' && b[2] == 'N' && b[3] == 'G') return pf::png_info(b.data(), b.size(), rows, cols);
     std::vector<uint8_t> px;                                                  // PPM: the header is all there is to parse
     return pf::read_image_file(filename, px, rows, cols);
 }

@@ -735,7 +735,7 @@ static bool ppm_header(const std::vector<uint8_t>& b, int& w, int& h, size_t& at
     return w > 0 && h > 0 && v[2] == 255;
 }
 
-// cv::imread(filename) for the two formats the file driver feeds from: JPEG (by its SOI) and binary PPM
+// cv::imread(filename) for the formats the file driver feeds from: JPEG (by its SOI), PNG (by its signature) and binary PPM
 static bool read_image_file_checked(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols);
 bool read_image_file(const char* filename, std::vector<uint8_t>& bgr, int* rows, int* cols)
 {
@@ -751,9 +751,13 @@ static bool read_image_file_checked(const char* filename, std::vector<uint8_t>& 
         if (!jpeg_info(b.data(), b.size(), &h, &w, nullptr)) return false;
         bgr.resize((size_t)w * h * 3);
         if (!jpeg_decode_bgr(b.data(), b.size(), bgr.data(), h, w, (size_t)w * 3)) return false;
+    } else if (b.size() >= 8 && b[0] == 0x89 && b[1] == 'P' && b[2] == 'N' && b[3] == 'G') {
+        if (!png_info(b.data(), b.size(), &h, &w)) return false;
+        bgr.resize((size_t)w * h * 3);
+        if (!png_decode_bgr(b.data(), b.size(), bgr.data(), h, w, (size_t)w * 3)) return false;
     } else {
         size_t at = 0;
-        if (!ppm_header(b, w, h, at) || b.size() - at < (size_t)w * h * 3) { set_error(std::string("unsupported image file (JPEG and binary PPM are read): ") + filename); return false; }
+        if (!ppm_header(b, w, h, at) || b.size() - at < (size_t)w * h * 3) { set_error(std::string("unsupported image file (JPEG, PNG and binary PPM are read): ") + filename); return false; }
         bgr.resize((size_t)w * h * 3);
         const uint8_t* s = b.data() + at;
         for (size_t i = 0; i < (size_t)w * h; i++) { bgr[3 * i] = s[3 * i + 2]; bgr[3 * i + 1] = s[3 * i + 1]; bgr[3 * i + 2] = s[3 * i]; }

@@ -63,10 +63,6 @@ class DroneMapDataset:
             if os.path.exists(base + ext):
                 if ext == ".npy":
                     return np.load(base + ext), pose
-                if ext in (".jpg", ".ppm"):
-                    from . import read_image                               # the library's own decoder (csrc/jpeg_decode.cpp)
-                    return read_image(base + ext), pose
-                from PIL import Image                                      # .png frames: not a format the reference's datasets use
-                rgb = np.asarray(Image.open(base + ext).convert("RGB"))
-                return np.ascontiguousarray(rgb[:, :, ::-1]), pose
+                from . import read_image                                   # the library's own readers (csrc/jpeg_decode.cpp, png_decode.cpp)
+                return read_image(base + ext), pose
         raise FileNotFoundError(base + ".jpg")
