@@ -251,7 +251,8 @@ def test_parallel_huffman_pass_equals_the_serial_pass(tmp_path):
     root = os.path.dirname(HERE)
     src = os.path.join(root, "pi-slam-fusion_amd", "csrc")
     exe = str(tmp_path / "huff_par_check")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + src, os.path.join(HERE, "cpp", "huff_par_check.cpp"), os.path.join(src, "jpeg_decode.cpp"), "-o", exe])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + src, os.path.join(HERE, "cpp", "huff_par_check.cpp"), os.path.join(src, "jpeg_decode.cpp"),
+                           os.path.join(src, "png_decode.cpp"), "-o", exe, "-lz"])
     files, want = [], []
     for i, (case, stream, _) in enumerate(vectors()):
         f = str(tmp_path / ("v%02d.jpg" % i))
