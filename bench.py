@@ -19,6 +19,8 @@ per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
 
 `value` is the device-resident rate: keyframes already in HBM, fed through pf_feed_device.  What a tracker feeding host frames
 gets per GPU is the `host_feed` record of the same line (pf_feed with its 36 MB H2D copy inside: PCIe-bound, ~1500 keyframes/s).
+A file-fed map -- the keyframe as the bytes of a .jpg, decoded on the GPU by pf_feed_jpeg -- is the `jpeg_feed` record (~530 keyframes/s on one
+host thread; the reference's cv::imread + feed on a host core: 13).
 
 Rank 0 prints ONE JSON line (contract in the task statement), including
   roofline     : dominant kernel; `achieved` / `frac` = SURVEY 8d's algorithmic bytes of the part of the canvases its timed launches
@@ -231,6 +233,38 @@ def host_feed_rate(pf, wl, poses, prep, frames_host, force_float, frames=60):
     return {"value": round(frames / dt, 1), "unit": "keyframes/s", "frames": frames,
             "h2d_GBps": round(nbytes * frames / dt / 1e9, 1),
             "note": "pageable host frames through pf_feed (36 MB H2D per keyframe inside feed)"}
+
+
+def jpeg_feed_rate(pf, wl, poses, prep, force_float, frames=60):
+    """The file driver's leg (the reference: cv::imread per keyframe, backup/map2dfusion.cpp:129-135): the keyframe as the bytes of a .jpg file
+    through pf_feed_jpeg -- decoded on the GPU (Huffman pass included for one-scan sequential streams), rendered from there.  One host thread.
+    Reported next to `value`, never as `value`.  Needs Pillow to WRITE the test stream (the product does not use it)."""
+    import io
+    from PIL import Image
+    # a picture a camera could have taken of something (the bench's keyframes are white noise, which no JPEG encoder is meant for):
+    # smooth waves + sigma-12 noise, tools/jpeg_rate.py's
+    h, w = CAM[1], CAM[0]
+    rng = np.random.default_rng(0)
+    y, x = np.mgrid[0:h, 0:w]
+    pic = ((np.sin(x / 37.0) * 60 + np.cos(y / 23.0) * 60 + 128)[..., None] + rng.normal(0, 12, (h, w, 3))).clip(0, 255).astype(np.uint8)
+    b = io.BytesIO()
+    Image.fromarray(pic).save(b, "JPEG", quality=90, subsampling=2)
+    stream = b.getvalue()
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float)
+    assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
+    for k in range(6):
+        assert m.feed_jpeg(stream, pose_at(poses, k))
+    m.sync()
+    t0 = time.perf_counter()
+    for k in range(6, 6 + frames):
+        assert m.feed_jpeg(stream, pose_at(poses, k))
+    m.sync()
+    dt = time.perf_counter() - t0
+    on_gpu, fell_back, rounds = pf.jpeg_huffman_counts(m)
+    m.close()
+    return {"value": round(frames / dt, 1), "unit": "keyframes/s", "frames": frames, "stream_MB": round(len(stream) / 1e6, 2),
+            "huffman_on_gpu_frames": on_gpu, "fell_back_frames": fell_back, "rounds": rounds,
+            "note": "4000x3000 4:2:0 q90 .jpg bytes (smooth waves + sigma-12 noise) through pf_feed_jpeg on one host thread: decode on the GPU + render"}
 
 
 def run_with_deadline(fn, seconds):
@@ -630,6 +664,7 @@ def main():
             out["cpu_baseline_allcores"] = guarded(cpu_baseline_allcores, force_float)
             if N == 1:
                 out["host_feed"] = guarded(host_feed_rate, pf, wl, my_sortie, prep, hostf, force_float)
+                out["jpeg_feed"] = guarded(jpeg_feed_rate, pf, wl, my_sortie, prep, force_float)
                 out["map2dcpu_single_band"] = guarded(map2dcpu_rates, pf, wl, my_sortie, prep, frames, hostf)
     if rank == 0:
         real_out.write(json.dumps(out) + "\n"); real_out.flush()
