@@ -648,6 +648,7 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
             for (int h = 0; h < bh; h++) {
                 if (bpm >= 10) return false;
                 P.comp_of[bpm] = i; P.hh[bpm] = h; P.vv[bpm] = v; P.dct[bpm] = td; P.act[bpm] = ta;
+                P.used |= (1u << td) | (1u << (4 + ta));
                 bpm++;
             }
         P.ch[i] = bh; P.cv[i] = bv; P.cbw[i] = k.bw; P.cblocks[i] = k.bw * k.bh;
@@ -660,6 +661,17 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
             static_assert(kParLook == kLookBits, "one table shape for both decoders");
             std::memcpy(o.look, h.look, sizeof(o.look)); std::memcpy(o.maxcode, h.maxcode, sizeof(o.maxcode));
             std::memcpy(o.valoff, h.valoff, sizeof(o.valoff)); std::memcpy(o.vals, h.vals, sizeof(o.vals));
+            for (int i = 0; i < (1 << kParLook); i++) {
+                const int len = h.look[i] >> 8, sym = h.look[i] & 255;
+                int bits = 0, adv = 0;
+                if (len) {
+                    if (!w) { bits = len + (sym & 15); adv = 1; }                     // DC: the difference's bits, then k = 1
+                    else if (sym & 15) { bits = len + (sym & 15); adv = (sym >> 4) + 1; }
+                    else if ((sym >> 4) == 15) { bits = len; adv = 16; }              // ZRL
+                    else { bits = len; adv = 64; }                                    // EOB (jdhuff.c: any run below 15 with size 0 ends the block)
+                }
+                o.adv[i] = (uint16_t)((bits << 8) | adv);
+            }
         }
     describe(dec, f);
     for (int i = 0; i < ns; i++) P.coef_off[i] = (uint32_t)f.c[i].coef_off;

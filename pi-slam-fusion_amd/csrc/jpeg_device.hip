@@ -262,9 +262,13 @@ struct HuffLds { HuffParTable tab[8]; uint32_t words[kStageWords]; };
 
 __device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, HuffLds& L, uint32_t first_sub)
 {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(P->tab);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(L.tab);
-    for (unsigned j = threadIdx.x; j < sizeof(L.tab) / 4; j += 256) dst[j] = src[j];
+    const uint32_t used = P->used;
+    for (int t = 0; t < 8; t++) {                                 // the tables the scan uses (four for a camera's frame)
+        if (!((used >> t) & 1u)) continue;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&P->tab[t]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&L.tab[t]);
+        for (unsigned j = threadIdx.x; j < sizeof(HuffParTable) / 4; j += 256) dst[j] = src[j];
+    }
     const uint32_t w0 = first_sub * (uint32_t)kSubWords, navail = ((P->nbits >> 3) + 16 + 3) / 4;      // the scan's bytes and the 16 zero bytes behind them
     for (unsigned j = threadIdx.x; j < (unsigned)kStageWords; j += 256) { const uint32_t w = w0 + j; L.words[j] = w < navail ? words[w] : 0u; }
     __syncthreads();

@@ -36,11 +36,15 @@ struct HuffParTable {
     int32_t  valoff[17];
     uint8_t  vals[256];
     int32_t  pad_;
+    // what the rounds need of a symbol and nothing else: prefix -> (bits of the code AND of its value << 8) | advance of k (a coefficient
+    // after a run r: r + 1; ZRL: 16; EOB: 64 = past the block's end; a DC symbol: 1), 0: the code is longer than the prefix
+    uint16_t adv[1 << kParLook];
 };
 struct HuffParPlan {
     uint32_t nbits;                           // entropy-coded bits (stuffing removed)
     int32_t  nsub;                            // subsequences: ceil(nbits / kSubBits)
     int32_t  bpm, total_blocks, mcux, mcuy, ncomp;
+    uint32_t used;                            // bit t: table t (0..3 DC, 4..7 AC) is one the scan uses
     int32_t  comp_of[10], hh[10], vv[10], dct[10], act[10];      // per block of an MCU: component, position inside the MCU, tables
     int32_t  ch[3], cv[3], cbw[3], cblocks[3];                   // per component: sampling factors, blocks per row held, blocks in all
     uint32_t coef_off[3];                                        // first coefficient of the component in the dense array (int16 units)
@@ -124,6 +128,13 @@ PF_HD void huff_par_sub(const HuffParPlan& P, const HuffParTable* __restrict__ t
     uint32_t n = 0;
     const HuffParCtl ctl = huff_par_ctl(P);
     while (p < limit) {
+        // the short way: one look-up says how far the symbol moves p and k (the values themselves are the write pass's business)
+        const uint32_t e = tabs[(int)(((k == 0 ? ctl.dc_pack : ctl.ac_pack) >> (4 * c)) & 15)].adv[peek16(words, p - bit0) >> (16 - kParLook)];
+        if (e) {
+            p += e >> 8; k += (int)(e & 255);
+            if (k >= 64) { n++; k = 0; c = c + 1 == ctl.bpm ? 0 : c + 1; }
+            continue;
+        }
         int wpos, value; bool done;
         huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
         n += done ? 1u : 0u;
