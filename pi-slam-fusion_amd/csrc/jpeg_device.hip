@@ -277,23 +277,32 @@ __device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint3
 // round 0: every subsequence from its own first bit as if a block began there; round r: from the end state its predecessor recorded in
 // round r - 1.  changed[r] is raised when a subsequence's result differs from the previous round's: a round that raises nothing is the fixed point.
 __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
-                                                     HuffParState* __restrict__ out, uint32_t* __restrict__ nblk, uint32_t* __restrict__ changed, int round)
+                                                     HuffParState* __restrict__ out, HuffParState* __restrict__ used, uint32_t* __restrict__ nblk,
+                                                     uint32_t* __restrict__ changed, int round)
 {
     __shared__ HuffLds L;
     const uint32_t first = blockIdx.x * 256u;
-    huff_stage(P, words, L, first);
     const int i = (int)(first + threadIdx.x);
-    if (i >= P->nsub) return;
+    const bool mine = i < P->nsub;
     HuffParState s0 = { 0u, 0u };
     if (round == 0) s0.p = (uint32_t)i * (uint32_t)kSubBits;
-    else if (i > 0) s0 = in[i - 1];
+    else if (mine && i > 0) s0 = in[i - 1];
+    // A subsequence entered in the state it was entered in the last time it was decoded ends as it ended then: only the subsequences whose
+    // predecessor moved have work, and a launch lasts as long as the slowest lane THAT HAS WORK (after a few rounds: a few per cent of them,
+    // rarely the one with 256 two-bit symbols in its 512 bits).  A workgroup none of whose lanes has work does not even stage its window.
+    bool active = mine;
+    if (round > 0 && mine) { const HuffParState u = used[i]; active = u.p != s0.p || u.ck != s0.ck; }
+    if (!__syncthreads_or(active ? 1 : 0)) { if (mine) out[i] = in[i]; return; }
+    huff_stage(P, words, L, first);
+    if (!mine) return;
+    if (!active) { out[i] = in[i]; return; }
     HuffParState e; uint32_t n;
     huff_par_sub(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, n);
     if (round > 0) {
         const HuffParState o = in[i];
         if (o.p != e.p || o.ck != e.ck || nblk[i] != n) changed[round] = 1u;
     }
-    out[i] = e; nblk[i] = n;
+    out[i] = e; nblk[i] = n; used[i] = s0;
 }
 
 // the write pass: coefficients into the dense array (zeroed before; DC values as differences), the last subsequence's end for the host to check
@@ -454,7 +463,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     Slot& s = slot_[i];
     const HuffParPlan* hp = (const HuffParPlan*)((char*)s.host + kHeaderBytes);
     const size_t S = (size_t)hp->nsub, wbytes = (s.par_bytes + 16 + 255) & ~(size_t)255;
-    const size_t o_st0 = kPlanBytes + wbytes, o_st1 = o_st0 + S * 8, o_nblk = o_st1 + S * 8, o_first = o_nblk + S * 4,
+    const size_t o_st0 = kPlanBytes + wbytes, o_st1 = o_st0 + S * 8, o_used = o_st1 + S * 8, o_nblk = o_used + S * 8, o_first = o_nblk + S * 4,
                  o_flags = (o_first + S * 4 + 255) & ~(size_t)255, o_tot = o_flags + kMaxRounds * 4 + 256;
     int cmax = 0;
     for (int c = 0; c < hp->ncomp; c++) cmax = std::max(cmax, hp->cblocks[c]);
@@ -471,6 +480,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     const HuffParPlan* P = (const HuffParPlan*)hb;
     const uint32_t* words = (const uint32_t*)(hb + kPlanBytes);
     HuffParState* stt[2] = { (HuffParState*)(hb + o_st0), (HuffParState*)(hb + o_st1) };
+    HuffParState* used = (HuffParState*)(hb + o_used);
     uint32_t* nblk = (uint32_t*)(hb + o_nblk); uint32_t* first = (uint32_t*)(hb + o_first);
     uint32_t* changed = (uint32_t*)(hb + o_flags); HuffParResult* res = (HuffParResult*)(hb + o_flags + kMaxRounds * 4);
     int* totals = (int*)(hb + o_tot);
@@ -478,7 +488,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     if (!hip_ok(hipMemsetAsync(changed, 0, kMaxRounds * 4 + 256, st), "flags")) return false;
     if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
     const dim3 grid((unsigned)((S + 255) / 256));
-    hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], nblk, changed, 0);
+    hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], used, nblk, changed, 0);
     // Rounds are launched in groups and the flags read back after each group (a read-back costs a stream synchronisation, a round past the
     // fixed point costs a launch that changes nothing).  Consecutive keyframes of a camera settle after about the same number of rounds: the
     // first group is the previous frame's count plus two, the following groups four rounds each.
@@ -487,7 +497,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     while (!settled && round + group < kMaxRounds) {
         for (int r = 0; r < group; r++) {
             round++;
-            hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], nblk, changed, round);
+            hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round);
             cur ^= 1;
         }
         if (!hip_ok(hipMemcpyAsync(res_host_, changed, kMaxRounds * 4, hipMemcpyDeviceToHost, st), "flags read-back")) return false;
