@@ -19,7 +19,7 @@ per GPU.  With N>1 the mosaic tiles are sharded by spatial hash:
 
 `value` is the device-resident rate: keyframes already in HBM, fed through pf_feed_device.  What a tracker feeding host frames
 gets per GPU is the `host_feed` record of the same line (pf_feed with its 36 MB H2D copy inside: PCIe-bound, ~1500 keyframes/s).
-A file-fed map -- the keyframe as the bytes of a .jpg, decoded on the GPU by pf_feed_jpeg -- is the `jpeg_feed` record (~650 keyframes/s on one
+A file-fed map -- the keyframe as the bytes of a .jpg, decoded on the GPU by pf_feed_jpeg -- is the `jpeg_feed` record (~750 keyframes/s on one
 host thread; the reference's cv::imread + feed on a host core: 13).
 
 Rank 0 prints ONE JSON line (contract in the task statement), including

@@ -274,35 +274,56 @@ __device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint3
     __syncthreads();
 }
 
-// round 0: every subsequence from its own first bit as if a block began there; round r: from the end state its predecessor recorded in
-// round r - 1.  changed[r] is raised when a subsequence's result differs from the previous round's: a round that raises nothing is the fixed point.
+// Launch 0: every subsequence from its own first bit as if a block began there, then sweeps from the end state its predecessor reached in the
+// sweep before; launch r: the same sweeps, seeded with launch r - 1's states (ping-pong arrays: a workgroup reads its left neighbour's last
+// subsequence as the previous launch left it).  changed[r] is raised when a subsequence's result moves during launch r: a launch that raises
+// nothing is the fixed point.
+constexpr int kSweeps = 8;                    // measured: 4 / 8 / 16 sweeps per launch = 629 / 600 / 694 us of rounds per 12 MP 4:2:0 frame
+constexpr int kMaxLaunches = 64;              // 512 sweeps: a stream that has not settled by then goes to the host's serial pass
 __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
                                                      HuffParState* __restrict__ out, HuffParState* __restrict__ used, uint32_t* __restrict__ nblk,
                                                      uint32_t* __restrict__ changed, int round)
 {
     __shared__ HuffLds L;
+    __shared__ HuffParState Es[257];                    // Es[0]: the end state of the subsequence left of the workgroup (as the previous launch left
+                                                        // it); Es[1 + t]: lane t's, updated from sweep to sweep
     const uint32_t first = blockIdx.x * 256u;
-    const int i = (int)(first + threadIdx.x);
+    const int t = (int)threadIdx.x, i = (int)(first + threadIdx.x);
     const bool mine = i < P->nsub;
-    HuffParState s0 = { 0u, 0u };
-    if (round == 0) s0.p = (uint32_t)i * (uint32_t)kSubBits;
-    else if (mine && i > 0) s0 = in[i - 1];
+    HuffParState cur = { 0u, 0u }, u = { 0xffffffffu, 0xffffffffu };      // this subsequence's end state; the state it was last entered in
+    uint32_t n = 0;
+    if (round > 0 && mine) { cur = in[i]; u = used[i]; n = nblk[i]; }
+    // (launch 0 knows nothing of the subsequence left of the workgroup: lane 0 keeps the guess it started from -- its own first bit, a block
+    // beginning there -- through all sweeps; the true start of the stream is that guess exactly)
+    if (t == 0) Es[0] = (round > 0 && first > 0) ? in[first - 1] : HuffParState{ first * (uint32_t)kSubBits, 0u };
+    Es[1 + t] = cur;
+    __syncthreads();
     // A subsequence entered in the state it was entered in the last time it was decoded ends as it ended then: only the subsequences whose
-    // predecessor moved have work, and a launch lasts as long as the slowest lane THAT HAS WORK (after a few rounds: a few per cent of them,
-    // rarely the one with 256 two-bit symbols in its 512 bits).  A workgroup none of whose lanes has work does not even stage its window.
-    bool active = mine;
-    if (round > 0 && mine) { const HuffParState u = used[i]; active = u.p != s0.p || u.ck != s0.ck; }
-    if (!__syncthreads_or(active ? 1 : 0)) { if (mine) out[i] = in[i]; return; }
-    huff_stage(P, words, L, first);
-    if (!mine) return;
-    if (!active) { out[i] = in[i]; return; }
-    HuffParState e; uint32_t n;
-    huff_par_sub(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, n);
-    if (round > 0) {
-        const HuffParState o = in[i];
-        if (o.p != e.p || o.ck != e.ck || nblk[i] != n) changed[round] = 1u;
+    // predecessor moved have work, and a sweep lasts as long as the slowest lane THAT HAS WORK.  A correction travels one subsequence per sweep;
+    // up to kSweeps sweeps run inside one launch (window and tables are staged once), so a chain inside a workgroup's 256 subsequences is
+    // followed without a launch per link.  A workgroup none of whose lanes has work does not even stage its window.
+    bool staged = false, moved = false;
+    for (int sweep = 0; sweep < kSweeps; sweep++) {
+        HuffParState s0;
+        if (round == 0 && sweep == 0) { s0.p = (uint32_t)i * (uint32_t)kSubBits; s0.ck = 0u; }
+        else s0 = Es[t];
+        const bool active = mine && (s0.p != u.p || s0.ck != u.ck) && s0.p >= (uint32_t)i * (uint32_t)kSubBits;      // (a start left of the subsequence cannot be: never decode from one)
+        if (!__syncthreads_or(active ? 1 : 0)) break;
+        if (!staged) { huff_stage(P, words, L, first); staged = true; }
+        HuffParState e = cur;
+        if (active) {
+            uint32_t nn;
+            huff_par_sub(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, nn);
+            moved = moved || e.p != cur.p || e.ck != cur.ck || nn != n;
+            n = nn; u = s0;
+        }
+        __syncthreads();                                // every lane has read its left neighbour's state of this sweep
+        if (active) { cur = e; Es[1 + t] = e; }
+        __syncthreads();
     }
-    out[i] = e; nblk[i] = n; used[i] = s0;
+    if (!mine) return;
+    out[i] = cur; nblk[i] = n; used[i] = u;
+    if (moved && round > 0) changed[round] = 1u;
 }
 
 // the write pass: coefficients into the dense array (zeroed before; DC values as differences), the last subsequence's end for the host to check
@@ -489,12 +510,12 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
     const dim3 grid((unsigned)((S + 255) / 256));
     hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], used, nblk, changed, 0);
-    // Rounds are launched in groups and the flags read back after each group (a read-back costs a stream synchronisation, a round past the
-    // fixed point costs a launch that changes nothing).  Consecutive keyframes of a camera settle after about the same number of rounds: the
-    // first group is the previous frame's count plus two, the following groups four rounds each.
+    // Launches (of up to kSweeps sweeps each) go out in groups and the flags are read back after each group (a read-back costs a stream
+    // synchronisation, a launch past the fixed point costs little: no workgroup has work).  Consecutive keyframes of a camera settle after about
+    // the same number of launches: the first group is the previous frame's count plus one, the following groups two launches each.
     int cur = 0, round = 0; bool settled = S == 1;
-    int group = std::min(std::max(settle_hint_ + 2, 4), (int)kMaxRounds - 1);
-    while (!settled && round + group < kMaxRounds) {
+    int group = std::min(std::max(settle_hint_ + 1, 2), (int)kMaxRounds - 1);
+    while (!settled && round + group < kMaxLaunches) {
         for (int r = 0; r < group; r++) {
             round++;
             hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round);
@@ -504,7 +525,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
         if (!hip_ok(hipStreamSynchronize(st), "Huffman rounds")) return false;
         const uint32_t* fl = (const uint32_t*)res_host_;
         for (int r = 1; r <= round && !settled; r++) if (fl[r] == 0) { settled = true; settle_hint_ = r; }
-        group = 4;
+        group = 2;
     }
     last_rounds_ = round;
     if (!settled) { skip_par_ = 15; return false; }          // (streams of quality 99 noise do this: ~250 rounds are 11 ms thrown away)

@@ -43,7 +43,7 @@ private:
     Bytes  last_ = { 0, 0, 0 };
     void*  huff_ = nullptr;   size_t huff_cap_ = 0;          // plan, scan bytes, subsequence states and counts of the parallel Huffman pass
     void*  res_host_ = nullptr;
-    int    last_rounds_ = 0, settle_hint_ = 14, skip_par_ = 0; long par_frames_ = 0, fallback_frames_ = 0;
+    int    last_rounds_ = 0, settle_hint_ = 4, skip_par_ = 0; long par_frames_ = 0, fallback_frames_ = 0;
 };
 
 }  // namespace pf

@@ -63,7 +63,7 @@ for name, kw in [("4:2:0 q90", dict(quality=90, subsampling=2)), ("4:2:0 q75", d
     hc = pf.jpeg_huffman_counts()
     rows.append((name, len(s) / 1e6, t_host, t_pil, t_dev, hc[2] if hc[0] > hc0[0] else 0))
     print("%-24s %.2f MB: host decode %.1f ms, Pillow %.1f ms, device decode %.1f ms per frame (Huffman pass on the GPU: %s)" %
-          (name, len(s) / 1e6, t_host * 1e3, t_pil * 1e3, t_dev * 1e3, ("%d rounds" % hc[2]) if rows[-1][5] else "no, host"), flush=True)
+          (name, len(s) / 1e6, t_host * 1e3, t_pil * 1e3, t_dev * 1e3, ("%d launches of up to 8 sweeps" % hc[2]) if rows[-1][5] else "no, host"), flush=True)
 
 # into a map: keyframes of the bench sortie as JPEG streams
 poses = wl.serpentine(cam, 100.0, a.frames + 4)
@@ -102,6 +102,6 @@ if a.md:
     with open(a.md, "w") as f:
         f.write("| stream (4000 x 3000) | size | host decode (`jpeg_decode.cpp`) | libjpeg-turbo via Pillow (SIMD) | device decode (`jpeg_device.hip`), host thread time per frame | Huffman pass |\n|---|---|---|---|---|---|\n")
         for (name, mb, th, tp, td, rounds) in rows:
-            f.write("| %s | %.2f MB | %.1f ms | %.1f ms | **%.1f ms** | %s |\n" % (name, mb, th * 1e3, tp * 1e3, td * 1e3, ("GPU, %d rounds" % rounds) if rounds else "host (serial)"))
+            f.write("| %s | %.2f MB | %.1f ms | %.1f ms | **%.1f ms** | %s |\n" % (name, mb, th * 1e3, tp * 1e3, td * 1e3, ("GPU, %d launches of sweeps" % rounds) if rounds else "host (serial)"))
         f.write("\ninto a map (fp32 pyramids, one host thread, the same mosaic both ways): `pf_feed_jpeg` **%.1f keyframes/s**, host decode + `pf_feed` %.1f keyframes/s\n" % (res["feed_jpeg"], res["decode_then_feed"]))
         f.write("\n`pf_feed_jpeg_batch` (Huffman passes of a batch side by side, %d host cores): **%s keyframes/s** with 4 / 8 / 16 frames and threads per batch\n" % (os.cpu_count(), " / ".join("%.0f" % res["batch%d" % n] for n in (4, 8, 16))))
