@@ -304,10 +304,13 @@ def strong_probe(pf, wl, torch, dist, rank, N, dev, frames, base, W, K, scale, f
         for k in range(lo, hi):
             assert m.feed_device(frames[k % len(frames)].data_ptr(), 3000, 4000, pose_at(base, k))
     run(0, Wp); m.sync()
+    import gc
+    gc.collect(); gc.disable()                 # as in timed_run: no interpreter heap collection inside the timed loop
     dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(Wp, Wp + Kp); m.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     rec = sh.strong_report(m, rank, N, backend)
@@ -340,13 +343,21 @@ def timed_run(m, run, W, K, event_every, barrier):
     dom = max(names, key=lambda n: prof[n]["ms"]) if W > 0 and any(prof[n]["launches"] for n in names) else "level0_fused"
     m.profile_reset()
     m.profile_enable(((2 + names.index(dom)) | (event_every << 8)) if event_every else 0)
+    import gc
     import torch
+    # The feed loop is Python: a full collection of the interpreter's heap (a million objects once torch is imported: ~40 ms) that happens to
+    # fall due inside the timed region is 4 keyframes' worth of stall per 200 -- and which run it hits depends on how many objects the
+    # command line allocated (measured: bench.py --no-cpu 3500-4000 keyframes/s for hours, one feed of the 200 taking 40 ms, while the same
+    # loop without the flag ran at 9600).  Collect before, none during.
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     run(W, W + K)
     m.sync()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    gc.enable()
     barrier()
     p = m.profile_read()[dom]
     m.profile_enable(0)
