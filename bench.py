@@ -637,9 +637,10 @@ def main():
     # the other pyramid type in the same run (the reference's default is CV_16SC3; north_star's parity bar is on fp32)
     if not args.no_cpu and N == 1:
         # the same run with the cull off: every tile of every keyframe's canvas rendered, as the reference does (same mosaic; what the
-        # headline gains by leaving out quadrants in which the keyframe cannot win the select).  In a child process of its own: the
-        # third timed run inside one process submits slowly on this stack (measured: 2400-4600 keyframes/s for runs that take their usual
-        # 150 us per launch) -- an artefact of the bench process, not of the engine; a fresh process shows the rate a user gets.
+        # headline gains by leaving out quadrants in which the keyframe cannot win the select).  In a child process of its own: rounds 3-4 saw
+        # the third timed run inside one process read 2400-4600 keyframes/s at its usual time per launch -- in round 5 found to be the
+        # interpreter's heap collection falling due inside the loop (timed_run now keeps it out); the child process stays: it also gives the
+        # leg a map store and a cull state of its own.
         def full_render():
             cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-cull", "--steps", str(K), "--warmup", str(W), "--scale", str(args.scale)]
             if args.int16:
