@@ -120,14 +120,14 @@ int     pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols);
 int     pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components);
 int     pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols);
 /* The same decode on the GPU (csrc/jpeg_device.hip), byte-equal to pf_jpeg_decode_bgr: the calling thread parses the markers;
- * sequential one-scan streams without restart intervals are Huffman-decoded on the GPU too (a self-synchronising parallel pass,
+ * sequential one-scan streams (with or without restart intervals) are Huffman-decoded on the GPU too (a self-synchronising parallel pass,
  * csrc/jpeg_huff_par.hpp), the others on the calling thread; kernels do libjpeg's dequantise + ISLOW IDCT, fancy upsampling and
  * colour conversion.  dev_bgr: rows*cols*3 bytes of device memory, complete in the order of `hip_stream`
  * (a hipStream_t, NULL = the default stream); the call returns when the work is queued.                               */
 int     pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream);
 /* Diagnostics: out = { frames whose Huffman pass ran on the GPU, frames that fell back to the host's serial pass after trying,
- * rounds the most recent GPU pass took } of the map's decoder (m = NULL: of pf_jpeg_decode_device's).  Sequential one-scan streams
- * without restart intervals take the GPU pass (csrc/jpeg_huff_par.hpp); PF_JPEG_HOST_HUFFMAN=1 keeps every stream on the host.  */
+ * launches the most recent GPU pass took } of the map's decoder (m = NULL: of pf_jpeg_decode_device's).  Sequential one-scan streams,
+ * with or without restart intervals, take the GPU pass (csrc/jpeg_huff_par.hpp); PF_JPEG_HOST_HUFFMAN=1 keeps every stream on the host.  */
 void    pf_debug_jpeg_huffman(pf_map* m, long long out[3]);
 /* Map2D::feed(cv::imread(imgfile), pose) in one call (backup/map2dfusion.cpp:129-135 + Map2DFusion.cpp:313-327): markers and
  * Huffman on the calling thread, then the frame is finished on the GPU straight into the slot in HBM a host frame would have

@@ -625,14 +625,16 @@ bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t*
 }
 
 // What the parallel Huffman pass (jpeg_huff_par.hpp) needs of a stream it is able to take -- sequential, ONE scan holding every component in
-// frame order, no restart interval, nothing but entropy-coded bytes up to EOI: the frame, the scan's tables and block layout, and the scan's
+// frame order, nothing but entropy-coded bytes (and, with a restart interval, RSTn markers in sequence) up to EOI: the frame, the scan's tables and block layout, and the scan's
 // bytes with the stuffing removed (into `bits`, 16 zero bytes after them).  false (quietly: it is a question, not an error) otherwise.
-bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes)
+bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes, std::vector<uint32_t>* seg_end)
 {
     if (!data || !bits) return false;
     Decoder dec(data, len);
     dec.plan_only = true;
-    if (!dec.read_headers(false) || !dec.sos_e || dec.progressive || dec.restart) return false;
+    if (!dec.read_headers(false) || !dec.sos_e || dec.progressive) return false;
+    if (dec.restart && !seg_end) return false;
+    if (seg_end) seg_end->clear();
     const uint8_t* d = data; const size_t s = dec.sos_s, e = dec.sos_e;
     const int ns = d[s];
     if (ns != dec.ncomp || e - s < (size_t)(4 + 2 * ns)) return false;
@@ -685,7 +687,8 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
         P.ch[0] = P.cv[0] = 1; P.cblocks[0] = P.mcux * P.mcuy;
     }
     P.total_blocks = P.mcux * P.mcuy * bpm;
-    // the scan's bytes without the stuffing, up to the marker that ends it -- which has to be EOI
+    // the scan's bytes without the stuffing, up to the marker that ends it -- which has to be EOI.  With a restart interval the RSTn markers
+    // are taken out too and the bit position of every one (the end of a segment; the encoder padded to a byte there) is recorded.
     const uint8_t* p = d + e; const uint8_t* end = d + len;
     size_t o = 0;
     for (;;) {
@@ -698,7 +701,14 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
         while (p < end && *p == 0xFF) p++;                                            // fill bytes
         if (p >= end) return false;
         if (*p == 0) { bits[o++] = 0xFF; p++; continue; }
-        if (*p != 0xD9) return false;                                                 // RSTn, DNL, another scan's tables: the serial pass's business
+        if (dec.restart && *p >= 0xD0 && *p <= 0xD7) {
+            if (*p != 0xD0 + (int)(seg_end->size() & 7) || o == 0 || o * 8 >= (1ull << 31)) return false;      // out of sequence: the serial pass's business
+            if (!seg_end->empty() && seg_end->back() == (uint32_t)(o * 8)) return false;                          // an empty segment
+            seg_end->push_back((uint32_t)(o * 8));
+            p++;
+            continue;
+        }
+        if (*p != 0xD9) return false;                                                 // DNL, another scan's tables, a stray RSTn: the serial pass's business
         break;
     }
     if (o == 0 || o * 8 >= (1ull << 31)) return false;
@@ -706,6 +716,15 @@ bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& 
     *nbytes = o;
     P.nbits = (uint32_t)(o * 8);
     P.nsub = (int32_t)((P.nbits + kSubBits - 1) / kSubBits);
+    if (dec.restart) {
+        const long mcus = ns > 1 ? (long)dec.mcux * dec.mcuy : (long)P.mcux * P.mcuy;
+        const long want = (mcus + dec.restart - 1) / dec.restart;
+        if (!seg_end->empty() && seg_end->back() == P.nbits) return false;           // a marker right before EOI
+        seg_end->push_back(P.nbits);
+        if ((long)seg_end->size() != want) return false;                             // not one segment per interval
+        P.rst_blocks = (uint32_t)(dec.restart * bpm);
+        P.nseg = (uint32_t)seg_end->size();
+    }
     return true;
 }
 

@@ -32,7 +32,8 @@ bool jpeg_frame_info(const uint8_t* data, size_t len, JpegFrame& f);
 bool jpeg_entropy_decode(const uint8_t* data, size_t len, JpegFrame& f, int16_t* store, size_t store_cap);
 struct HuffParPlan;            // jpeg_huff_par.hpp
 // the plan of a parallel Huffman pass over the stream's one scan, and the scan's bytes with the stuffing removed; false when the stream is not of that kind
-bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes);
+// (seg_end: where the ends of the restart intervals' segments go; nullptr: streams with a restart interval are refused)
+bool jpeg_scan_plan(const uint8_t* data, size_t len, JpegFrame& f, HuffParPlan& P, uint8_t* bits, size_t cap, size_t* nbytes, std::vector<uint32_t>* seg_end = nullptr);
 // PNG (png_decode.cpp): cv::imread's default conversion to three 8-bit channels, BGR; non-interlaced files
 bool png_info(const uint8_t* data, size_t len, int* rows, int* cols);
 bool png_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols, size_t stride);

@@ -1,7 +1,7 @@
 // jpeg_device.hip -- cv::imread's JPEG leg (backup/map2dfusion.cpp:129-132) on the GPU, byte-equal to jpeg_decode.cpp and therefore to
 // libjpeg-turbo (tests/test_gpu_jpeg.py); integer arithmetic throughout.
-//   Huffman pass   for the streams cameras write (sequential, one scan, no restart interval) the host parses the headers and strips the byte
-//                  stuffing; the scan's bytes cross PCIe and are decoded one thread per 512-bit subsequence in rounds until a round changes
+//   Huffman pass   for the streams cameras write (sequential, one scan, with or without restart intervals) the host parses the headers and
+//                  strips the byte stuffing and the RSTn markers; the scan's bytes cross PCIe and are decoded one thread per 512-bit subsequence in rounds until a round changes
 //                  nothing (jpeg_huff_par.hpp; k_huff_round, k_scan_*, k_huff_write).  Any other stream, and any stream whose write pass
 //                  does not end exactly on the frame's last block, is entropy-decoded on the host (jpeg_decode.cpp) and its coefficients
 //                  uploaded (2 B per sample: the size of the frame they become).
@@ -184,6 +184,18 @@ __global__ __launch_bounds__(256) void k_jpeg_colour(const JpegDevFrame* __restr
         for (int i = 0; i < 3 * n; i++) dst[i] = o[i];
 }
 
+// Restart intervals reset the DC prediction (jdhuff.c process_restart): a component's DC value is the running sum of its differences since the
+// start of its interval -- the global running sum (k_scan_apply<2>) minus the one at the last block before the interval.
+__global__ __launch_bounds__(256) void k_dc_restart(const HuffParPlan* __restrict__ P, const int* __restrict__ sums, int dc_stride, int16_t* __restrict__ coef)
+{
+    const int comp = (int)blockIdx.y, N = P->cblocks[comp], j = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (j >= N) return;
+    const int group = (int)(P->rst_blocks / (uint32_t)P->bpm) * P->ch[comp] * P->cv[comp];
+    const int g0 = j / group * group;
+    const int* sc = sums + comp * dc_stride;
+    coef[huff_par_comp_block(*P, comp, (uint32_t)j)] = (int16_t)(sc[j] - (g0 ? sc[g0 - 1] : 0));
+}
+
 // The shapes cameras write (three components, luma at full resolution, both chroma planes expanded HE x VE in {1x1, 2x1, 2x2} with
 // more than two samples a row, cols a multiple of 8): eight pixels of a row per thread -- the luma bytes in one load, the chroma
 // samples of the row (and of its neighbour row for 2x2) as one word plus the two samples next to it, 24 bytes out in six words.
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256) void k_jpeg_colour8(const JpegDevFrame* __rest
 }
 
 // ---- the Huffman pass in parallel (jpeg_huff_par.hpp): one thread per subsequence of kSubBits bits
-struct HuffParResult { uint32_t g_end, p, ck, pad_; };
+struct HuffParResult { uint32_t g_end, p, ck, bad; };            // bad: a restart segment did not end on its last block
 
 // A workgroup's 256 subsequences are contiguous in the stream: their words (plus what a symbol starting on the window's last bit may
 // still read) and the code tables are staged in LDS once -- a symbol costs two or three dependent look-ups, and from L2 those were the whole
@@ -280,9 +292,10 @@ __device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint3
 // nothing is the fixed point.
 constexpr int kSweeps = 8;                    // measured: 4 / 8 / 16 sweeps per launch = 629 / 600 / 694 us of rounds per 12 MP 4:2:0 frame
 constexpr int kMaxLaunches = 64;              // 512 sweeps: a stream that has not settled by then goes to the host's serial pass
+template <bool RST>
 __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
                                                      HuffParState* __restrict__ out, HuffParState* __restrict__ used, uint32_t* __restrict__ nblk,
-                                                     uint32_t* __restrict__ changed, int round)
+                                                     uint32_t* __restrict__ changed, int round, const uint32_t* __restrict__ seg_end, const uint32_t* __restrict__ seg_hint)
 {
     __shared__ HuffLds L;
     __shared__ HuffParState Es[257];                    // Es[0]: the end state of the subsequence left of the workgroup (as the previous launch left
@@ -313,7 +326,7 @@ __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restric
         HuffParState e = cur;
         if (active) {
             uint32_t nn;
-            huff_par_sub(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, nn);
+            huff_par_sub<RST>(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, e, nn, seg_end, RST ? seg_hint[i] : 0u);
             moved = moved || e.p != cur.p || e.ck != cur.ck || nn != n;
             n = nn; u = s0;
         }
@@ -327,8 +340,10 @@ __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restric
 }
 
 // the write pass: coefficients into the dense array (zeroed before; DC values as differences), the last subsequence's end for the host to check
+template <bool RST>
 __global__ __launch_bounds__(256) void k_huff_write(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ st,
-                                                     const uint32_t* __restrict__ first_block, int16_t* __restrict__ coef, HuffParResult* __restrict__ res)
+                                                     const uint32_t* __restrict__ first_block, int16_t* __restrict__ coef, HuffParResult* __restrict__ res,
+                                                     const uint32_t* __restrict__ seg_end, const uint32_t* __restrict__ seg_hint)
 {
     __shared__ HuffLds L;
     const uint32_t first = blockIdx.x * 256u;
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(256) void k_huff_write(const HuffParPlan* __restric
     HuffParState s0 = { 0u, 0u };
     if (i > 0) s0 = st[i - 1];
     HuffParState e; uint32_t ge;
-    huff_par_write(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, first_block[i], coef, e, ge);
+    huff_par_write<RST>(*P, L.tab, L.words, first * (uint32_t)kSubBits, i, s0, first_block[i], coef, e, ge, seg_end, RST ? seg_hint[i] : 0u, &res->bad);
     if (i == P->nsub - 1) { res->g_end = ge; res->p = e.p; res->ck = e.ck; }
 }
 
@@ -349,7 +364,7 @@ constexpr int kScanPer = 4, kScanTile = 256 * kScanPer;
 template <int MODE>
 __device__ inline int scan_elem(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, const int16_t* __restrict__ coef, int comp, int j)
 {
-    return MODE == 0 ? (int)nblk[j] : (int)coef[huff_par_comp_block(*P, comp, (uint32_t)j)];
+    return MODE == 0 ? (int)nblk[j] : (int)coef[huff_par_comp_block(*P, comp, (uint32_t)j)];          // (MODE 2 reads what MODE 1 reads)
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scan_totals(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, const int16_t* __restrict__ coef,
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_scan_top(int* __restrict__ totals, int
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void k_scan_apply(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ nblk, int16_t* __restrict__ coef,
-                                                     uint32_t* __restrict__ first_block, const int* __restrict__ totals, int stride)
+                                                     uint32_t* __restrict__ first_block, const int* __restrict__ totals, int stride, int dc_stride)
 {
     __shared__ int part[256];
     const int comp = (int)blockIdx.y, N = MODE == 0 ? P->nsub : P->cblocks[comp], t = (int)threadIdx.x;
@@ -409,7 +424,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const HuffParPlan* __restric
     for (int e = 0; e < kScanPer; e++) {
         if (j0 + e >= N) break;
         if (MODE == 0) { first_block[j0 + e] = (uint32_t)run; run += v[e]; }
-        else { run += v[e]; coef[huff_par_comp_block(*P, comp, (uint32_t)(j0 + e))] = (int16_t)run; }
+        else if (MODE == 1) { run += v[e]; coef[huff_par_comp_block(*P, comp, (uint32_t)(j0 + e))] = (int16_t)run; }
+        else { run += v[e]; reinterpret_cast<int*>(first_block)[comp * dc_stride + j0 + e] = run; }          // MODE 2: the running sum itself (restart intervals)
     }
 }
 
@@ -445,7 +461,7 @@ bool JpegDevice::prepare(int i, const uint8_t* data, size_t len, int rows, int c
     if (rows > 0 && (s.f.rows != rows || s.f.cols != cols)) { set_error("jpeg device: the output buffer does not have the image's size"); return false; }
     if (s.f.coef_count >= (1ull << 31)) { set_error("jpeg device: image too large"); return false; }
     size_t need = kHeaderBytes + s.f.coef_count * sizeof(int16_t);
-    need = std::max(need, kHeaderBytes + kPlanBytes + len + 64);          // the parallel pass's layout: header, plan, the scan's bytes
+    need = std::max(need, kHeaderBytes + kPlanBytes + len + 1024 + (len / 2 + len / 64 + 16) * 4);          // the parallel pass's layout: header, plan, the scan's bytes, restart tables
     s.data = data; s.len = len; s.par = false;
     if (s.done && s.used && !hip_ok(hipEventSynchronize((hipEvent_t)s.done), "wait for the staging buffer")) return false;
     s.used = false;
@@ -469,7 +485,24 @@ bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
         // a stream the parallel pass takes: its scan's bytes (stuffing removed) and the plan go to the GPU, nothing else happens here
         HuffParPlan* plan = (HuffParPlan*)((char*)s.host + kHeaderBytes);
         uint8_t* bits = (uint8_t*)s.host + kHeaderBytes + kPlanBytes;
-        if (jpeg_scan_plan(data, len, s.f, *plan, bits, s.cap - kHeaderBytes - kPlanBytes, &s.par_bytes)) { s.par = true; s.staged = true; return true; }
+        std::vector<uint32_t> seg;
+        if (jpeg_scan_plan(data, len, s.f, *plan, bits, s.cap - kHeaderBytes - kPlanBytes, &s.par_bytes, &seg)) {
+            // restart intervals: the segments' ends and, per subsequence, the first segment that ends after its first bit, behind the scan's bytes
+            const size_t wbytes = (s.par_bytes + 16 + 255) & ~(size_t)255, S = (size_t)plan->nsub;
+            s.aux_words = 0;
+            if (plan->rst_blocks) {
+                if (kHeaderBytes + kPlanBytes + wbytes + (seg.size() + 1 + S) * 4 <= s.cap) {
+                    uint32_t* aux = (uint32_t*)((char*)s.host + kHeaderBytes + kPlanBytes + wbytes);
+                    std::memcpy(aux, seg.data(), seg.size() * 4);
+                    aux[seg.size()] = plan->nbits;                                          // a guard behind the last end
+                    uint32_t* hint = aux + seg.size() + 1;
+                    uint32_t sg = 0;
+                    for (size_t k = 0; k < S; k++) { while (seg[sg] <= (uint32_t)k * (uint32_t)kSubBits) sg++; hint[k] = sg; }
+                    s.aux_words = seg.size() + 1 + S;
+                    s.par = true; s.staged = true; return true;
+                }
+            } else { s.par = true; s.staged = true; return true; }
+        }
     }
     s.staged = jpeg_entropy_decode(data, len, s.f, (int16_t*)((char*)s.host + kHeaderBytes), s.f.coef_count);
     if (!s.staged) s.err = last_error();
@@ -484,12 +517,17 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     Slot& s = slot_[i];
     const HuffParPlan* hp = (const HuffParPlan*)((char*)s.host + kHeaderBytes);
     const size_t S = (size_t)hp->nsub, wbytes = (s.par_bytes + 16 + 255) & ~(size_t)255;
-    const size_t o_st0 = kPlanBytes + wbytes, o_st1 = o_st0 + S * 8, o_used = o_st1 + S * 8, o_nblk = o_used + S * 8, o_first = o_nblk + S * 4,
+    const bool rst = hp->rst_blocks != 0;
+    const size_t aux_bytes = rst ? ((s.aux_words * 4 + 255) & ~(size_t)255) : 0;
+    const size_t o_st0 = kPlanBytes + wbytes + aux_bytes, o_st1 = o_st0 + S * 8, o_used = o_st1 + S * 8, o_nblk = o_used + S * 8, o_first = o_nblk + S * 4,
                  o_flags = (o_first + S * 4 + 255) & ~(size_t)255, o_tot = o_flags + kMaxRounds * 4 + 256;
     int cmax = 0;
     for (int c = 0; c < hp->ncomp; c++) cmax = std::max(cmax, hp->cblocks[c]);
     const int stride = (int)std::max((S + kScanTile - 1) / kScanTile, (size_t)(cmax + kScanTile - 1) / kScanTile) + 1;
-    const size_t total = o_tot + (size_t)stride * 3 * 4;
+    size_t dc_total = 0; int dc_stride = 0;
+    if (rst) { dc_stride = cmax; dc_total = (size_t)cmax * 3 * 4; }
+    const size_t o_dc = (o_tot + (size_t)stride * 3 * 4 + 255) & ~(size_t)255;
+    const size_t total = o_dc + dc_total;
     if (huff_cap_ < total) {
         if (huff_) (void)hipFree(huff_);
         huff_ = nullptr; huff_cap_ = 0;
@@ -505,11 +543,15 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     uint32_t* nblk = (uint32_t*)(hb + o_nblk); uint32_t* first = (uint32_t*)(hb + o_first);
     uint32_t* changed = (uint32_t*)(hb + o_flags); HuffParResult* res = (HuffParResult*)(hb + o_flags + kMaxRounds * 4);
     int* totals = (int*)(hb + o_tot);
-    if (!hip_ok(hipMemcpyAsync(hb, (char*)s.host + kHeaderBytes, kPlanBytes + s.par_bytes + 16, hipMemcpyHostToDevice, st), "scan upload")) return false;
+    int* dcsum = (int*)(hb + o_dc);
+    const uint32_t* seg_end = rst ? (const uint32_t*)(hb + kPlanBytes + wbytes) : nullptr;
+    const uint32_t* seg_hint = rst ? seg_end + hp->nseg + 1 : nullptr;
+    if (!hip_ok(hipMemcpyAsync(hb, (char*)s.host + kHeaderBytes, rst ? kPlanBytes + wbytes + s.aux_words * 4 : kPlanBytes + s.par_bytes + 16, hipMemcpyHostToDevice, st), "scan upload")) return false;
     if (!hip_ok(hipMemsetAsync(changed, 0, kMaxRounds * 4 + 256, st), "flags")) return false;
     if (!hip_ok(hipMemsetAsync((char*)dev_ + kHeaderBytes, 0, coef_bytes, st), "coefficient clear")) return false;
     const dim3 grid((unsigned)((S + 255) / 256));
-    hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], used, nblk, changed, 0);
+    if (rst) hipLaunchKernelGGL((k_huff_round<true>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], used, nblk, changed, 0, seg_end, seg_hint);
+    else hipLaunchKernelGGL((k_huff_round<false>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[1], stt[0], used, nblk, changed, 0, seg_end, seg_hint);
     // Launches (of up to kSweeps sweeps each) go out in groups and the flags are read back after each group (a read-back costs a stream
     // synchronisation, a launch past the fixed point costs little: no workgroup has work).  Consecutive keyframes of a camera settle after about
     // the same number of launches: the first group is the previous frame's count plus one, the following groups two launches each.
@@ -518,7 +560,8 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     while (!settled && round + group < kMaxLaunches) {
         for (int r = 0; r < group; r++) {
             round++;
-            hipLaunchKernelGGL(k_huff_round, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round);
+            if (rst) hipLaunchKernelGGL((k_huff_round<true>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round, seg_end, seg_hint);
+            else hipLaunchKernelGGL((k_huff_round<false>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round, seg_end, seg_hint);
             cur ^= 1;
         }
         if (!hip_ok(hipMemcpyAsync(res_host_, changed, kMaxRounds * 4, hipMemcpyDeviceToHost, st), "flags read-back")) return false;
@@ -533,17 +576,22 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     const int tiles_s = (int)((S + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL((k_scan_totals<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, totals, stride, tiles_s, 0, 0);
-    hipLaunchKernelGGL((k_scan_apply<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride);
-    hipLaunchKernelGGL(k_huff_write, grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, dcoef, res);
+    hipLaunchKernelGGL((k_scan_apply<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride, 0);
+    if (rst) hipLaunchKernelGGL((k_huff_write<true>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, dcoef, res, seg_end, seg_hint);
+    else hipLaunchKernelGGL((k_huff_write<false>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], (const uint32_t*)first, dcoef, res, seg_end, seg_hint);
     int tc[3] = { 0, 0, 0 }, tmax = 0;
     for (int c = 0; c < hp->ncomp; c++) { tc[c] = (hp->cblocks[c] + kScanTile - 1) / kScanTile; tmax = std::max(tmax, tc[c]); }
     hipLaunchKernelGGL((k_scan_totals<1>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);
     hipLaunchKernelGGL(k_scan_top, dim3((unsigned)hp->ncomp), dim3(1024), 0, st, totals, stride, tc[0], tc[1], tc[2]);
-    hipLaunchKernelGGL((k_scan_apply<1>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride);
+    if (rst) {
+        hipLaunchKernelGGL((k_scan_apply<2>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, (uint32_t*)dcsum, (const int*)totals, stride, dc_stride);
+        hipLaunchKernelGGL(k_dc_restart, dim3((unsigned)((cmax + 255) / 256), (unsigned)hp->ncomp), dim3(256), 0, st, P, (const int*)dcsum, dc_stride, dcoef);
+    } else
+        hipLaunchKernelGGL((k_scan_apply<1>), dim3((unsigned)tmax, (unsigned)hp->ncomp), dim3(256), 0, st, P, (const uint32_t*)nblk, dcoef, first, (const int*)totals, stride, 0);
     if (!hip_ok(hipMemcpyAsync(res_host_, res, sizeof(HuffParResult), hipMemcpyDeviceToHost, st), "result read-back")) return false;
     if (!hip_ok(hipStreamSynchronize(st), "Huffman write pass")) return false;
     const HuffParResult* r = (const HuffParResult*)res_host_;
-    return r->g_end == (uint32_t)hp->total_blocks && r->ck == 0 && hp->nbits - r->p < 8;
+    return r->g_end == (uint32_t)hp->total_blocks && r->ck == 0 && hp->nbits - r->p < 8 && r->bad == 0;
 }
 
 // ... step 3 (calling thread): the coefficients get to the GPU -- decoded there, or uploaded -- and the two kernels follow on `stream`

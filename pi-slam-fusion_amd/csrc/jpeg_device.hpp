@@ -30,7 +30,7 @@ private:
     struct Slot {
         void* host = nullptr; size_t cap = 0; void* done = nullptr; bool used = false, staged = false; JpegFrame f; std::string err;
         const uint8_t* data = nullptr; size_t len = 0;        // the stream (the caller's, valid until submit): a fallback decodes it again
-        bool par = false; size_t par_bytes = 0;              // staged for the Huffman pass on the GPU: the scan's bytes, stuffing removed
+        bool par = false; size_t par_bytes = 0, aux_words = 0;   // staged for the Huffman pass on the GPU: the scan's bytes (stuffing removed), restart tables
     };
     enum { kMaxRounds = 256 };
     bool huffman_on_device(int i, void* stream, size_t coef_bytes);

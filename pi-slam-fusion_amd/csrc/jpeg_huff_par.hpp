@@ -14,8 +14,9 @@
 //             now exact start states writes the coefficients (DC values still as differences) into the dense array the IDCT kernel reads;
 //   DC        a running sum per component in scan order turns the differences into values (jdhuff.c: last_dc_val).
 // The stream handed over has its byte stuffing removed (jpeg_scan_plan); the decode of a symbol is jdhuff.c's, statement for
-// statement the one of jpeg_decode.cpp's block_sequential.  Streams this does not take -- progressive, several scans, restart intervals,
-// a marker inside the scan -- and streams whose write pass does not end exactly on the last block keep the host's serial pass.
+// statement the one of jpeg_decode.cpp's block_sequential.  Restart intervals: the RSTn markers are removed too, the ends of their segments
+// recorded, no symbol is read across one, the DC running sums start over per interval.  Streams this does not take -- progressive, several
+// scans, a marker other than RSTn inside the scan -- and streams whose write pass does not end exactly on the last block keep the host's serial pass.
 #pragma once
 #include <cstdint>
 
@@ -45,6 +46,9 @@ struct HuffParPlan {
     int32_t  nsub;                            // subsequences: ceil(nbits / kSubBits)
     int32_t  bpm, total_blocks, mcux, mcuy, ncomp;
     uint32_t used;                            // bit t: table t (0..3 DC, 4..7 AC) is one the scan uses
+    // restart intervals (DRI): the stream handed over has its RSTn markers removed; segment s ends at bit seg_end[s] (a byte boundary, the
+    // last one = nbits) and holds rst_blocks blocks (the last segment what is left); 0: no restart interval
+    uint32_t rst_blocks, nseg;
     int32_t  comp_of[10], hh[10], vv[10], dct[10], act[10];      // per block of an MCU: component, position inside the MCU, tables
     int32_t  ch[3], cv[3], cbw[3], cblocks[3];                   // per component: sampling factors, blocks per row held, blocks in all
     uint32_t coef_off[3];                                        // first coefficient of the component in the dense array (int16 units)
@@ -118,26 +122,46 @@ PF_HD void huff_par_step(const HuffParCtl& P, const HuffParTable* __restrict__ t
     if (done) { k = 0; c = c + 1 == P.bpm ? 0 : c + 1; }
 }
 
+// Restart intervals: a decoder never reads across the end B of its segment -- the encoder pads the last byte of a segment with one-bits, which
+// are the prefix of no code, so the true decode meets at most seven bits there that only make a symbol together with the next segment's; a
+// symbol that would end beyond B is therefore not a symbol: the decoder steps to B and starts over (block 0 of an MCU, DC first), as
+// jdhuff.c's process_restart does.  `s` = index of the segment p lies in.
+PF_HD void huff_par_seg_find(const uint32_t* __restrict__ seg_end, uint32_t hint, uint32_t p, uint32_t& s, uint32_t& B)
+{
+    s = hint;
+    B = seg_end[s];
+    while (B <= p) { s++; B = seg_end[s]; }              // ends at nbits > p: terminates
+}
+
 // Subsequence i decoded from `start` to its end: the state there and the blocks completed on the way
+template <bool RST>
 PF_HD void huff_par_sub(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, uint32_t bit0, int i,
-                        HuffParState start, HuffParState& end, uint32_t& nblk)
+                        HuffParState start, HuffParState& end, uint32_t& nblk, const uint32_t* __restrict__ seg_end = nullptr, uint32_t seg_hint = 0)
 {
     const uint64_t lim64 = (uint64_t)(i + 1) * kSubBits;
     const uint32_t limit = lim64 < P.nbits ? (uint32_t)lim64 : P.nbits;
     uint32_t p = start.p; int c = (int)(start.ck & 255), k = (int)(start.ck >> 8);
     uint32_t n = 0;
     const HuffParCtl ctl = huff_par_ctl(P);
+    uint32_t sg = 0, B = 0xffffffffu;
+    if (RST && p < limit) huff_par_seg_find(seg_end, seg_hint, p, sg, B);
     while (p < limit) {
+        const uint32_t p0 = p; const int c0 = c, k0 = k; const uint32_t n0 = n;
         // the short way: one look-up says how far the symbol moves p and k (the values themselves are the write pass's business)
         const uint32_t e = tabs[(int)(((k == 0 ? ctl.dc_pack : ctl.ac_pack) >> (4 * c)) & 15)].adv[peek16(words, p - bit0) >> (16 - kParLook)];
         if (e) {
             p += e >> 8; k += (int)(e & 255);
             if (k >= 64) { n++; k = 0; c = c + 1 == ctl.bpm ? 0 : c + 1; }
-            continue;
+        } else {
+            int wpos, value; bool done;
+            huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
+            n += done ? 1u : 0u;
         }
-        int wpos, value; bool done;
-        huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
-        n += done ? 1u : 0u;
+        if (RST && p >= B) {
+            if (p > B) { n = n0; (void)p0; (void)c0; (void)k0; }          // not a symbol: padding
+            p = B; c = 0; k = 0;
+            if (p < P.nbits) { sg++; B = seg_end[sg]; }
+        }
     }
     end.p = p; end.ck = (uint32_t)c | ((uint32_t)k << 8);
     nblk = n;
@@ -153,9 +177,11 @@ PF_HD uint32_t huff_par_block_base(const HuffParPlan& P, uint32_t mcu, int c)
 }
 
 // The write pass of subsequence i: from the exact start state, in the block with index `g` (blocks completed before the subsequence).
-// Returns false when the decode leaves the frame (more blocks than the frame holds): the stream is not one this decoder takes.
+// `bad` is raised when a segment does not end on its last block (restart intervals): the stream is not one this decoder takes.
+template <bool RST>
 PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__ tabs, const uint32_t* __restrict__ words, uint32_t bit0, int i,
-                          HuffParState start, uint32_t g, int16_t* __restrict__ coef, HuffParState& end, uint32_t& g_end)
+                          HuffParState start, uint32_t g, int16_t* __restrict__ coef, HuffParState& end, uint32_t& g_end,
+                          const uint32_t* __restrict__ seg_end = nullptr, uint32_t seg_hint = 0, uint32_t* __restrict__ bad = nullptr)
 {
     const uint64_t lim64 = (uint64_t)(i + 1) * kSubBits;
     const uint32_t limit = lim64 < P.nbits ? (uint32_t)lim64 : P.nbits;
@@ -163,13 +189,28 @@ PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__
     const uint32_t total = (uint32_t)P.total_blocks;
     uint32_t base = g < total ? huff_par_block_base(P, g / (uint32_t)P.bpm, c) : 0u;
     const HuffParCtl ctl = huff_par_ctl(P);
+    uint32_t sg = 0, B = 0xffffffffu;
+    if (RST && p < limit) huff_par_seg_find(seg_end, seg_hint, p, sg, B);
     while (p < limit && g < total) {
         int wpos, value; bool done;
         huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
+        if (RST && p > B) {                                   // padding at the end of the segment: nothing to write, the next segment starts over
+            p = B; c = 0; k = 0; done = false; wpos = -1;
+            if (g != (sg + 1) * P.rst_blocks && bad) *bad = 1u;
+            if (g < total) base = huff_par_block_base(P, g / (uint32_t)P.bpm, 0);
+            if (p < P.nbits) { sg++; B = seg_end[sg]; }
+            continue;
+        }
         if (wpos >= 0 && value != 0) coef[base + (uint32_t)wpos] = (int16_t)value;
         if (done) {
             g++;
             if (g < total) base = huff_par_block_base(P, g / (uint32_t)P.bpm, c);
+        }
+        if (RST && p == B) {                                  // the segment ended on a byte boundary without padding
+            if ((c != 0 || k != 0 || g != (sg + 1) * P.rst_blocks) && g < total && bad) *bad = 1u;
+            c = 0; k = 0;
+            if (g < total) base = huff_par_block_base(P, g / (uint32_t)P.bpm, 0);
+            if (p < P.nbits) { sg++; B = seg_end[sg]; }
         }
     }
     end.p = p; end.ck = (uint32_t)c | ((uint32_t)k << 8);

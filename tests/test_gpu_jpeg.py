@@ -158,12 +158,13 @@ def test_feed_jpeg_batch_builds_the_same_mosaic_as_one_by_one(pf, thread):
 
 
 def test_huffman_pass_runs_on_the_gpu_for_one_scan_streams_and_on_the_host_for_the_rest(pf):
-    """the streams a camera writes (sequential, one scan, no restart interval) are entropy-decoded on the GPU too (csrc/jpeg_huff_par.hpp);
+    """the streams a camera writes (sequential, one scan, with or without restart intervals) are entropy-decoded on the GPU too (csrc/jpeg_huff_par.hpp);
     everything else keeps the host's serial pass -- the pixels are the host decoder's either way"""
     Image = pytest.importorskip("PIL.Image")
     a = picture(600, 800, 42)
     for kw, on_gpu in [({"quality": 85, "subsampling": 2}, True), ({"quality": 100, "subsampling": 0}, True), ({"quality": 50, "subsampling": 1, "optimize": True}, True),
-                       ({"quality": 85, "subsampling": 2, "progressive": True}, False), ({"quality": 85, "subsampling": 2, "restart_marker_blocks": 7}, False)]:
+                       ({"quality": 85, "subsampling": 2, "progressive": True}, False), ({"quality": 85, "subsampling": 2, "restart_marker_blocks": 7}, True),
+                       ({"quality": 92, "subsampling": 1, "restart_marker_rows": 1}, True), ({"quality": 40, "subsampling": 0, "restart_marker_blocks": 1}, True)]:
         b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", **kw); s = b.getvalue()
         g0, f0, _ = pf.jpeg_huffman_counts()
         assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s)), kw
@@ -232,3 +233,39 @@ def test_device_decode_random_streams(pf):
     # nearly all of them Huffman-decoded on the GPU: one (quality 99 noise) does not settle within the round limit and falls back, and the
     # consumer then leaves its next 15 streams to the host
     assert g1[0] - g0[0] >= n - 20 and g1[1] - g0[1] <= 2, (g0, g1)
+
+
+def test_restart_interval_streams_on_the_gpu(pf):
+    """DRI streams (what camera hardware often writes): RSTn markers are taken out on the host, the parallel pass respects the segment ends and
+    resets the DC predictions per interval -- the pixels are the host decoder's, the Huffman pass ran on the GPU, and a stream with a damaged
+    segment falls back to the serial pass with the serial pass's pixels"""
+    Image = pytest.importorskip("PIL.Image")
+    from PIL import ImageFile
+    ImageFile.MAXBLOCK = max(ImageFile.MAXBLOCK, 1 << 24)
+    n = 0
+    g0 = pf.jpeg_huffman_counts()
+    for (h, w) in [(17, 33), (64, 48), (240, 320), (481, 643), (1080, 1920)]:
+        a = picture(h, w, 5 * h + w)
+        for sub in (0, 1, 2):
+            for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 3}, {"restart_marker_rows": 1}, {"restart_marker_rows": 2, "optimize": True}):
+                for mode in ("RGB", "L"):
+                    b = io.BytesIO()
+                    Image.fromarray(a).convert(mode).save(b, "JPEG", quality=[35, 90, 97][n % 3], subsampling=sub, **kw)
+                    s = b.getvalue()
+                    assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s)), (h, w, sub, kw, mode)
+                    n += 1
+        for samp in [((1, 2), (1, 1), (1, 1)), ((2, 2), (2, 1), (1, 2))]:
+            for r in (1, 2, 5):
+                s = jpeg_enc.encode(a[:min(h, 130), :min(w, 250)], samp, restart=r)
+                assert np.array_equal(on_device(pf, s), pf.decode_jpeg(s)), (h, w, samp, r)
+                n += 1
+    g1 = pf.jpeg_huffman_counts()
+    assert g1[0] - g0[0] == n and g1[1] == g0[1], (g0, g1, n)
+    # damage inside a segment: the segment no longer ends on its last block -> serial pass, same pixels
+    a = picture(240, 320, 77)
+    b = io.BytesIO(); Image.fromarray(a).save(b, "JPEG", quality=85, subsampling=2, restart_marker_rows=1)
+    s = bytearray(b.getvalue()); mid = len(s) * 2 // 3
+    while s[mid] == 0xFF or s[mid - 1] == 0xFF or s[mid + 1] == 0xFF:
+        mid += 1
+    s[mid] ^= 0x5A
+    assert np.array_equal(on_device(pf, bytes(s)), pf.decode_jpeg(bytes(s)))

@@ -246,7 +246,8 @@ def test_damaged_streams_are_decoded_or_refused_never_worse(pf):
 def test_parallel_huffman_pass_equals_the_serial_pass(tmp_path):
     """csrc/jpeg_huff_par.hpp -- what the GPU runs one thread per 512-bit subsequence -- run in host loops (tests/cpp/huff_par_check.cpp)
     over the golden streams: every stream the plan takes gives the serial pass's coefficients and ends exactly on the frame's last block;
-    progressive streams, restart intervals and one-scan-per-component streams are left to the serial pass"""
+    restart intervals included (markers taken out, segment ends respected, DC predictions reset); progressive and one-scan-per-component
+    streams are left to the serial pass"""
     import subprocess
     root = os.path.dirname(HERE)
     src = os.path.join(root, "pi-slam-fusion_amd", "csrc")
@@ -258,14 +259,14 @@ def test_parallel_huffman_pass_equals_the_serial_pass(tmp_path):
         f = str(tmp_path / ("v%02d.jpg" % i))
         open(f, "wb").write(stream)
         files.append(f)
-        serial_only = bool(case.get("progressive") or case.get("restart_marker_blocks") or case.get("restart_marker_rows") or case.get("restart") or case.get("interleaved") is False)
+        serial_only = bool(case.get("progressive") or case.get("interleaved") is False)
         want.append(not serial_only)
     # more shapes: every sampling the encoder of tests/jpeg_enc.py writes, 16-bit codes, sizes around the subsequence length
     for j, (h, w, samp, kw) in enumerate([(40, 56, ((2, 2), (1, 1), (1, 1)), {}), (33, 47, ((1, 2), (1, 1), (1, 1)), {"long_codes": True}), (130, 250, ((4, 1), (1, 1), (1, 1)), {}),
                                           (130, 250, ((2, 2), (2, 1), (1, 2)), {"colour": "rgb"}), (9, 7, ((1, 1), (1, 1), (1, 1)), {"q16": True, "q": 3}), (200, 300, ((2, 1), (1, 1), (1, 1)), {"restart": 5})]):
         f = str(tmp_path / ("e%02d.jpg" % j))
         open(f, "wb").write(jpeg_enc.encode(picture(h, w, 11 * j + 1), samp, **kw))
-        files.append(f); want.append("restart" not in kw)
+        files.append(f); want.append(True)
     r = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     lines = r.stdout.decode().strip().split("\n")
     assert r.returncode == 0 and len(lines) == len(files), r.stdout.decode()

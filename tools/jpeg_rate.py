@@ -37,6 +37,7 @@ if a.decode_only:
     sys.exit(0)
 rows = []
 for name, kw in [("4:2:0 q90", dict(quality=90, subsampling=2)), ("4:2:0 q75", dict(quality=75, subsampling=2)), ("4:4:4 q90", dict(quality=90, subsampling=0)),
+                 ("4:2:0 q90, restart interval = one MCU row", dict(quality=90, subsampling=2, restart_marker_rows=1)),
                  ("4:2:0 q90 progressive", dict(quality=90, subsampling=2, progressive=True))]:
     b = io.BytesIO(); Image.fromarray(pic).save(b, "JPEG", **kw); s = b.getvalue()
     n = a.frames
