@@ -225,6 +225,9 @@ FusionMap::~FusionMap()
         if (i < kMarks && mark_ev_[i]) (void)hipEventDestroy(mark_ev_[i]);
     }
     for (int i = 0; i < kMaxLevels; i++) { g_[i].release(); wgt_[i].release(); blend_lv_[i].release(); }
+    for (int i = 0; i < 2; i++) { if (out_pin_[i]) (void)hipHostFree(out_pin_[i]); if (out_copied_[i]) (void)hipEventDestroy(out_copied_[i]); }
+    if (out_ready_) (void)hipEventDestroy(out_ready_);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     blend_src_.release(); blend_out_raw_.release(); blend_out_bgr_.release(); mosaic_table_.release(); w8_.release(); wmap_.release();
     store_.clear();
     (void)hipStreamDestroy(stream_);
@@ -1627,13 +1630,169 @@ bool FusionMap::blend_tiles(const std::vector<std::pair<int, int>>& tiles, const
     return true;
 }
 
+// ------------------------------------------------------------------ output side
+// Results leave HBM through a ring of two pinned staging slots: the device-to-host copy of piece k+1 (copy_stream_) runs while
+// the host moves piece k from its slot into the caller's (pageable) buffer on a few threads.  A blocking hipMemcpy into
+// pageable memory -- what rounds 1-5 did -- moves 12 GB/s on the boxes used; a caller who hands over pinned memory
+// (pf_host_alloc) gets the copy straight into it.
+static void copy_threads(void* dst, const void* src, size_t bytes, int nthreads)
+{
+    if (nthreads <= 1 || bytes < ((size_t)4 << 20)) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t part = ((bytes / nthreads) + 4095) & ~(size_t)4095;
+    for (int i = 1; i < nthreads; i++) {
+        const size_t o = part * i;
+        if (o >= bytes) break;
+        th.emplace_back([=] { std::memcpy((char*)dst + o, (const char*)src + o, std::min(part, bytes - o)); });
+    }
+    std::memcpy(dst, src, std::min(part, bytes));
+    for (auto& t : th) t.join();
+}
+
+static bool is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+bool FusionMap::out_ring_init()
+{
+    if (out_pin_[0]) return true;
+    for (int i = 0; i < 2; i++) {
+        HIP_OK(hipHostMalloc((void**)&out_pin_[i], kOutSlot, hipHostMallocDefault));
+        HIP_OK(hipEventCreateWithFlags(&out_copied_[i], hipEventDisableTiming));
+    }
+    HIP_OK(hipEventCreateWithFlags(&out_ready_, hipEventDisableTiming));
+    HIP_OK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    const unsigned hc = std::thread::hardware_concurrency();
+    out_threads_ = std::getenv("PF_COPY_THREADS") ? std::atoi(std::getenv("PF_COPY_THREADS")) : (int)std::min(8u, std::max(1u, hc / 2));
+    return true;
+}
+
+// `pieces` = (host destination, device source, bytes) in the order they become ready; everything they read has been queued on
+// stream_ before the call.  Pieces are cut to the slot size.
+bool FusionMap::download(const std::vector<OutPiece>& pieces)
+{
+    if (pieces.empty()) return true;
+    if (!out_ring_init()) return false;
+    HIP_OK(hipEventRecord(out_ready_, stream_));
+    HIP_OK(hipStreamWaitEvent(copy_stream_, out_ready_, 0));
+    struct Part { char* dst; const char* src; size_t n; bool direct; };
+    std::vector<Part> parts;
+    for (auto& pc : pieces) {
+        const bool direct = is_pinned_host(pc.dst);
+        for (size_t o = 0; o < pc.bytes; o += kOutSlot) parts.push_back({ (char*)pc.dst + o, (const char*)pc.src + o, std::min(kOutSlot, pc.bytes - o), direct });
+    }
+    int k = 0;                                  // staged parts issued so far
+    long prev = -1; int prev_slot = 0;          // staged part whose bytes still sit in its slot
+    auto drain = [&]() -> bool {
+        if (prev < 0) return true;
+        HIP_OK(hipEventSynchronize(out_copied_[prev_slot]));
+        copy_threads(parts[prev].dst, out_pin_[prev_slot], parts[prev].n, out_threads_);
+        prev = -1;
+        return true;
+    };
+    for (size_t i = 0; i < parts.size(); i++) {
+        const Part& pt = parts[i];
+        if (pt.direct) { HIP_OK(hipMemcpyAsync(pt.dst, pt.src, pt.n, hipMemcpyDeviceToHost, copy_stream_)); continue; }
+        const int slot = k++ & 1;               // its previous tenant (two staged parts ago) has been drained: drain() runs once per staged part
+        HIP_OK(hipMemcpyAsync(out_pin_[slot], pt.src, pt.n, hipMemcpyDeviceToHost, copy_stream_));
+        HIP_OK(hipEventRecord(out_copied_[slot], copy_stream_));
+        if (!drain()) return false;             // the part before this one, while this one is on the wire
+        prev = (long)i; prev_slot = slot;
+    }
+    if (!drain()) return false;
+    HIP_OK(hipStreamSynchronize(copy_stream_));
+    return true;
+}
+
 // ------------------------------------------------------------------ blend
 // Ele::blend (.cpp:77-146) for a list of tiles.  halo9 (nullptr, or 9 device pointers per tile) substitutes packed strip
-// sets for neighbours held by other shards.  Results land in tile order; the tiles are processed in chunks whose pixels
-// come back in ONE device-to-host copy each.
+// sets for neighbours held by other shards.  Results land in tile order (a tile that does not exist leaves the caller's
+// bytes alone).  One launch of the fused collapse kernel per kBlendLaunch tiles, "blend with neighbours" and "blend by self"
+// tiles side by side in it; the pixels come back through download().
 bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host)
 {
     Section sec(this, T_UPDATE_TEXTURE);
+#if PF_EXPERIMENTS
+    static const bool per_level = std::getenv("PF_BLEND_PER_LEVEL") != nullptr;
+    if (per_level) return blend_batch_per_level(tiles, halo9, raw_host, bgr_host);
+#endif
+    const int nl = band_num_ + 1;
+    const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
+    const size_t tile_px = (size_t)kElePixels * kElePixels;
+    if (!settle()) return false;                  // the upper levels of the last frames are still pending: run them first (stream order)
+    // algorithmic bytes of one blended tile: its own Laplacians and level-0 weights read, the result written, plus the ring of
+    // neighbour pixels the crop depends on at levels >= 1 (pyrUp reaches one pixel per level: collapse_fused.hip)
+    double tile_bytes[2] = { 0, 0 };
+    for (int nb = 0; nb < 2; nb++) {
+        double b = (double)tile_px * 4 + (raw_host ? (double)tile_px * px : 0) + (bgr_host ? (double)tile_px * 3 : 0);
+        int lo = 0, hi = kElePixels - 1;
+        for (int i = 0; i < nl; i++) {
+            const int ts = kElePixels >> i;
+            if (i > 0) { lo = (lo - 1) >> 1; hi = (hi >> 1) + 1; }            // relative to the tile's own square
+            const int bd = nb ? 1 << (nl - 1 - i) : 0, l = std::max(lo, -bd), h = std::min(hi, ts - 1 + bd);
+            b += (double)(h - l + 1) * (h - l + 1) * px;
+            (void)ts;
+        }
+        tile_bytes[nb] = b;
+    }
+    constexpr size_t kBlendLaunch = 1024;         // tiles per launch: bounds the result buffers in HBM (fp32 raw: 805 MB)
+    for (size_t c0 = 0; c0 < tiles.size(); c0 += kBlendLaunch) {
+        const size_t cn = std::min(kBlendLaunch, tiles.size() - c0);
+        std::vector<BlendJob> jobs; jobs.reserve(cn);
+        double bytes = 0;
+        for (size_t t = c0; t < c0 + cn; t++) {
+            Tile* self = store_.find(tiles[t].first, tiles[t].second);
+            if (!self || self->fresh) continue;
+            const void* const* halo = halo9 ? halo9 + 9 * t : nullptr;
+            BlendJob jb{}; bool all = opt_.high_quality_show != 0;
+            for (int dy = -1; dy <= 1 && all; dy++)
+                for (int dx = -1; dx <= 1; dx++) {
+                    const int j = 3 * (dy + 1) + dx + 1;
+                    Tile* n = store_.find(tiles[t].first + dx, tiles[t].second + dy);
+                    if (n && !n->fresh) jb.src[j] = (uint64_t)(uintptr_t)n->base;
+                    else if (halo && halo[j]) { jb.src[j] = (uint64_t)(uintptr_t)halo[j]; jb.strip_mask |= 1u << j; }
+                    else { all = false; break; }
+                }
+            if (!all) { for (auto& q : jb.src) q = 0; jb.strip_mask = 0; }
+            jb.src[4] = (uint64_t)(uintptr_t)self->base;
+            jb.border = all ? 1 : 0; jb.out = (int)(t - c0);
+            jobs.push_back(jb);
+            bytes += tile_bytes[jb.border];
+        }
+        if (jobs.empty()) continue;
+        if (raw_host && !blend_out_raw_.reserve(tile_px * px * cn)) return false;
+        if (bgr_host && !blend_out_bgr_.reserve(tile_px * 3 * cn)) return false;
+        if (!blend_src_.reserve(jobs.size() * sizeof(BlendJob))) return false;
+        HIP_OK(hipMemcpyAsync(blend_src_.p, jobs.data(), jobs.size() * sizeof(BlendJob), hipMemcpyHostToDevice, stream_));
+        prof_begin(K_BLEND_FUSED, bytes);
+        launch_blend_fused(stream_, lay_, (const BlendJob*)blend_src_.p, (int)jobs.size(), raw_host ? blend_out_raw_.p : nullptr,
+                           bgr_host ? (uint8_t*)blend_out_bgr_.p : nullptr);
+        prof_end();
+        HIP_OK(hipGetLastError());
+        // runs of tiles that exist, each one piece per output
+        std::vector<OutPiece> pieces;
+        for (size_t a = 0; a < jobs.size();) {
+            size_t b = a + 1;
+            while (b < jobs.size() && jobs[b].out == jobs[b - 1].out + 1) b++;
+            const size_t r0 = (size_t)jobs[a].out, n = b - a;
+            if (bgr_host) pieces.push_back({ bgr_host + (c0 + r0) * tile_px * 3, (char*)blend_out_bgr_.p + r0 * tile_px * 3, n * tile_px * 3 });
+            if (raw_host) pieces.push_back({ (char*)raw_host + (c0 + r0) * tile_px * px, (char*)blend_out_raw_.p + r0 * tile_px * px, n * tile_px * px });
+            a = b;
+        }
+        if (!download(pieces)) return false;      // also orders the next launch's job upload and result buffers after this one's readers
+        HIP_OK(hipStreamSynchronize(stream_));    // jobs (pageable) were read by an async copy
+    }
+    return true;
+}
+
+#if PF_EXPERIMENTS
+// The per-level form of rounds 1-5 (A/B partner and second opinion of the fused kernel): padded squares per level in HBM,
+// one launch per reference op, one blocking device-to-host copy per 128-tile chunk.
+bool FusionMap::blend_batch_per_level(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host)
+{
     const int nl = band_num_ + 1, L = band_num_;
     const size_t es = lay_.f32 ? 4 : 2, px = 3 * es;
     const size_t tile_px = (size_t)kElePixels * kElePixels;
@@ -1714,6 +1873,8 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
     }
     return true;
 }
+
+#endif
 
 bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo)
 {
@@ -1811,25 +1972,39 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     HIP_OK(sync_all());
     if (!mosaic_table_.reserve(tab.size() * 8)) return false;
     HIP_OK(hipMemcpy(mosaic_table_.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
-    for (int i = 0; i <= L; i++) {
-        const size_t n = (size_t)(*rows >> i) * (*cols >> i);
-        if (!blend_lv_[i].reserve(n * px)) return false;
-        prof_begin(K_MOSAIC_GATHER, (double)n * px * 2);
-        launch_mosaic_gather(stream_, lay_, i, (const uint64_t*)mosaic_table_.p, wx, wy, blend_lv_[i].p);
-        prof_end();
-    }
-    for (int i = L; i > 0; i--) {
-        prof_begin(K_COLLAPSE, (double)(*rows >> (i - 1)) * (*cols >> (i - 1)) * px * 2.25);
-        launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, 0, blend_lv_[i].p, 0, *rows >> (i - 1), *cols >> (i - 1), 1);
-        prof_end();
-    }
     const size_t out_bytes = (size_t)*rows * *cols * 3;
     if (!blend_out_bgr_.reserve(out_bytes)) return false;
-    prof_begin(K_SAVE_FINISH, (double)*rows * *cols * (px + 4 + 3));
-    launch_save_finish(stream_, lay_, blend_lv_[0].p, (const uint64_t*)mosaic_table_.p, wx, wy, opt_.bg_color, (uint8_t*)blend_out_bgr_.p);
+#if PF_EXPERIMENTS
+    static const bool per_level = std::getenv("PF_BLEND_PER_LEVEL") != nullptr;
+    if (per_level) {                              // rounds 1-5: paste per level, one collapse launch per level, finish
+        for (int i = 0; i <= L; i++) {
+            const size_t n = (size_t)(*rows >> i) * (*cols >> i);
+            if (!blend_lv_[i].reserve(n * px)) return false;
+            prof_begin(K_MOSAIC_GATHER, (double)n * px * 2);
+            launch_mosaic_gather(stream_, lay_, i, (const uint64_t*)mosaic_table_.p, wx, wy, blend_lv_[i].p);
+            prof_end();
+        }
+        for (int i = L; i > 0; i--) {
+            prof_begin(K_COLLAPSE, (double)(*rows >> (i - 1)) * (*cols >> (i - 1)) * px * 2.25);
+            launch_collapse(stream_, lay_.f32, blend_lv_[i - 1].p, 0, blend_lv_[i].p, 0, *rows >> (i - 1), *cols >> (i - 1), 1);
+            prof_end();
+        }
+        prof_begin(K_SAVE_FINISH, (double)*rows * *cols * (px + 4 + 3));
+        launch_save_finish(stream_, lay_, blend_lv_[0].p, (const uint64_t*)mosaic_table_.p, wx, wy, opt_.bg_color, (uint8_t*)blend_out_bgr_.p);
+        prof_end();
+        HIP_OK(sync_all());
+        HIP_OK(hipMemcpy(bgr, blend_out_bgr_.p, out_bytes, hipMemcpyDeviceToHost));
+        return true;
+    }
+#endif
+    // one launch: paste, collapse in LDS, 8U, background (collapse_fused.hip).  Algorithmic bytes: every tile's Laplacians and
+    // level-0 weights read once, the mosaic written once.
+    double P = 0; for (int i = 0; i <= L; i++) P += 1.0 / (double)(1 << (2 * i));
+    prof_begin(K_SAVE_FUSED, (double)cnt * kElePixels * kElePixels * (P * px + 4) + (double)out_bytes);
+    launch_save_fused(stream_, lay_, (const uint64_t*)mosaic_table_.p, wx, wy, opt_.bg_color, (uint8_t*)blend_out_bgr_.p);
     prof_end();
-    HIP_OK(sync_all());
-    HIP_OK(hipMemcpy(bgr, blend_out_bgr_.p, out_bytes, hipMemcpyDeviceToHost));
+    HIP_OK(hipGetLastError());
+    if (!download({ { bgr, blend_out_bgr_.p, out_bytes } })) return false;
     return true;
 }
 

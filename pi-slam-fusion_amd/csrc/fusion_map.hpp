@@ -269,8 +269,20 @@ private:
     bool flush_pipeline();
     bool settle();
 
-    // blend / save scratch
+    // blend / save scratch (blend_lv_: the per-level form of the experiments library only)
     DevBuf blend_lv_[kMaxLevels], blend_src_, blend_out_raw_, blend_out_bgr_, mosaic_table_, strip_desc_;
+    // results on their way to the host: two pinned staging slots, filled on copy_stream_ while the host empties the other one
+    static constexpr size_t kOutSlot = (size_t)32 << 20;
+    struct OutPiece { void* dst; const void* src; size_t bytes; };      // host destination, device source
+    uint8_t*    out_pin_[2]{};
+    hipEvent_t  out_copied_[2]{}, out_ready_ = nullptr;
+    hipStream_t copy_stream_ = nullptr;
+    int         out_threads_ = 1;
+    bool out_ring_init();
+    bool download(const std::vector<OutPiece>& pieces);
+#if PF_EXPERIMENTS
+    bool blend_batch_per_level(const std::vector<std::pair<int,int>>& tiles, const void* const* halo9, void* raw_host, uint8_t* bgr_host);
+#endif
 
     // frame staging + feed queue
     std::vector<FrameSlot> slots_;

@@ -2539,7 +2539,7 @@ TileLayout make_layout(int band_num, bool f32)
 const char* kernel_name(int id)
 {
     static const char* n[K_COUNT] = { "warp", "pyrdown_img", "pyrdown_w", "lap_select", "blend_gather", "collapse",
-                                      "blend_finish", "mosaic_gather", "save_finish", "level0_fused", "level_fused", "single_band" };
+                                      "blend_finish", "mosaic_gather", "save_finish", "level0_fused", "level_fused", "single_band", "blend_fused", "save_fused" };
     return (id >= 0 && id < K_COUNT) ? n[id] : "?";
 }
 

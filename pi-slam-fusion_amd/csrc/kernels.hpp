@@ -48,9 +48,20 @@ struct BlendSrc {
     int         is_strip;
 };
 
+// one tile of a fused blend launch (collapse_fused.hip): the 3 x 3 sources of Ele::blend's assembly (.cpp:93-117; row-major, [4] = the
+// tile itself), each a tile slot or -- bit j of strip_mask -- a packed halo strip set of another shard
+struct BlendJob {
+    uint64_t src[9];        // device addresses; only [4] is read when border == 0
+    uint32_t strip_mask;
+    int      border;        // 1: all nine present, padded squares with border 1 << (L - i); 0: "blend by self" (.cpp:131-145)
+    int      out;           // tile index in the output arrays
+    int      pad_;
+};
+static_assert(sizeof(BlendJob) == 88, "BlendJob is copied to LDS by words");
+
 // kernel ids for the profile table
 enum KernelId { K_WARP = 0, K_PYRDOWN_IMG, K_PYRDOWN_W, K_LAP_SELECT, K_BLEND_GATHER, K_COLLAPSE,
-                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_LEVEL0, K_LEVEL, K_SINGLE, K_COUNT };
+                K_BLEND_FINISH, K_MOSAIC_GATHER, K_SAVE_FINISH, K_LEVEL0, K_LEVEL, K_SINGLE, K_BLEND_FUSED, K_SAVE_FUSED, K_COUNT };
 const char* kernel_name(int id);
 
 void launch_warp(hipStream_t s, bool f32, const uint8_t* src, const WarpArgs& a, void* g0, float* w0);
@@ -110,6 +121,13 @@ int  read_select_counts(unsigned long long* out, int reset);       // diagnostic
 int  level0_need_reach(const TileLayout& lay, int table_n, int nrect0);
 int  level_block_rows(bool f32);                                     // block height of the pipelined level kernel (fused = 1)      // diagnostics (PF_STAMP=1)
 
+// Ele::blend (+ the 8U view) of n tiles / save()'s paste + collapse + 8U + background: ONE launch each, the pyramid collapsed in LDS
+// (collapse_fused.hip).  jobs_dev / table_dev in device memory; raw_out (pyramid type, n x 256 x 256 x 3) and bgr_out may be null
+void launch_blend_fused(hipStream_t s, const TileLayout& lay, const BlendJob* jobs_dev, int n, void* raw_out, uint8_t* bgr_out);
+void launch_save_fused(hipStream_t s, const TileLayout& lay, const uint64_t* table_dev, int wx, int wy, int bg, uint8_t* bgr_out);
+
+// The per-level form of rounds 1-5 (one padded square per level in HBM, one launch per reference op): kept in the experiments library
+// as the A/B partner and second opinion of the fused kernel (PF_BLEND_PER_LEVEL=1, tests/test_gpu_variants.py)
 // blend(): gather padded level images for `batch` tiles (9 sources each), collapse, finish
 void launch_blend_gather(hipStream_t s, const TileLayout& lay, int level, int border, const BlendSrc* srcs,
                          void* dst, size_t dst_stride_bytes, int batch);

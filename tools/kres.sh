@@ -3,13 +3,14 @@
 # (compiles kernels.hip to /tmp/kb with -save-temps)
 set -e
 flt=$1; shift || true
+src=${PF_KRES_SRC:-kernels}
 cd "$(dirname "$0")/../pi-slam-fusion_amd/csrc"
 mkdir -p /tmp/kb
-/opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 $PF_EXTRA_FLAGS "$@" -c -save-temps=obj -o /tmp/kb/kernels.o -x hip kernels.hip 2>&1 | grep -E "error|warning: [^s]" || true
-python3 - "$flt" <<'PY'
+/opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 $PF_EXTRA_FLAGS "$@" -c -save-temps=obj -o /tmp/kb/$src.o -x hip $src.hip 2>&1 | grep -E "error|warning: [^s]" || true
+python3 - "$flt" "$src" <<'PY'
 import re, sys
 flt = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else 'k_levels'
-s = open('/tmp/kb/kernels-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+s = open('/tmp/kb/%s-hip-amdgcn-amd-amdhsa-gfx950.s' % sys.argv[2]).read()
 md = s[s.find('amdhsa.kernels'):]
 for b in md.split('  - .agpr_count')[1:]:
     n = re.search(r'\.name:\s+(\S+)', b).group(1)
