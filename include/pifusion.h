@@ -162,6 +162,15 @@ int     pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr256);
 /* batch form of the draw() loop (.cpp:705-742): blend every tile whose
  * Ischanged flag is set, clear the flags; xy/bgr sized by cap tiles.       */
 int     pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap);
+/* Ele::blend + the 8U view for a caller-chosen list of n tiles (xy = n pairs ix, iy), Ischanged left alone: what a viewer that
+ * re-draws a region calls.  bgr: n x 256 x 256 x 3; a tile without pyramid leaves its 196 608 bytes untouched.  One launch
+ * per 1024 tiles.  Returns 1 / 0.                                           */
+int     pf_blend_tiles(pf_map* m, const int* xy, int n, uint8_t* bgr);
+/* Page-locked host memory for the output side: results written into such a buffer (pf_blend_changed, pf_blend_tiles,
+ * pf_save_to_memory) are copied from HBM straight into it; any other buffer is filled through the library's own pinned
+ * staging ring and a host copy (the counterpart of cv::Mat's allocator for the textures updateTexture hands to GL).       */
+void*   pf_host_alloc(size_t bytes);
+void    pf_host_free(void* p);
 /* The text draw() hands to scommand.Call("MapWidget", ...) for a refreshed tile when Fuse2Google is set
  * (MultiBandMap2DCPU.cpp:744-757): "Map2DUpdate LastTexMat <lng lat 0 of the tile's top-left corner> <... bottom-right>".
  * Byte for byte the reference's string: tile corners rounded to float first (.cpp:709-712), plane * corner, then

@@ -21,6 +21,19 @@ NoType, TypeCPU, TypeGPU, TypeMultiBandCPU, TypeRender = 0, 1, 2, 3, 4
 PF_8UC3, PF_8UC4, PF_16SC3, PF_32FC3 = 16, 24, 19, 21
 
 
+def host_array(shape, dtype=np.uint8):
+    """numpy array over page-locked host memory (pf_host_alloc); freed with the array."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib().pf_host_alloc(n)
+    if not p:
+        raise MemoryError("pf_host_alloc(%d)" % n)
+    buf = (C.c_uint8 * n).from_address(p)
+    a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+    import weakref
+    weakref.finalize(buf, lib().pf_host_free, p)
+    return a
+
+
 class Options(C.Structure):
     _fields_ = [("band_number", C.c_int), ("force_float", C.c_int), ("high_quality_show", C.c_int),
                 ("weight_type", C.c_int), ("bg_color", C.c_int), ("resolution", C.c_double),
@@ -102,6 +115,10 @@ def lib():
     L.pf_blend_tile_raw.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_tile.argtypes = [vp, C.c_int, C.c_int, vp]
     L.pf_blend_changed.argtypes = [vp, ip, vp, C.c_int]
+    if hasattr(L, "pf_blend_tiles") or not os.environ.get("PF_LIB"):
+        L.pf_blend_tiles.argtypes = [vp, ip, C.c_int, vp]
+        L.pf_host_alloc.argtypes = [C.c_size_t]; L.pf_host_alloc.restype = vp
+        L.pf_host_free.argtypes = [vp]; L.pf_host_free.restype = None
     L.pf_format_map_update.argtypes = [dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.pf_map_update_command.argtypes = [vp, C.c_int, C.c_int, dp, C.c_char_p, C.c_int]
     L.pf_lnglat_from_distance.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]; L.pf_lnglat_from_distance.restype = None
@@ -368,11 +385,12 @@ class Map2D:
     def save(self, filename):
         return bool(lib().pf_save(self._h, filename.encode()))
 
-    def save_to_memory(self):
+    def save_to_memory(self, alloc=None):
+        """(mosaic BGR8, (tile x0, tile y0)); alloc(shape) -> uint8 array supplies the buffer (e.g. host_array)."""
         r, c, x0, y0 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         if not lib().pf_save_to_memory(self._h, None, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
             return None
-        out = np.empty((r.value, c.value, 3), np.uint8)
+        out = alloc((r.value, c.value, 3)) if alloc else np.empty((r.value, c.value, 3), np.uint8)
         if not lib().pf_save_to_memory(self._h, out.ctypes.data, C.byref(r), C.byref(c), C.byref(x0), C.byref(y0)):
             return None
         return out, (x0.value, y0.value)
@@ -424,11 +442,22 @@ class Map2D:
         n = lib().pf_map_update_command(self._h, ix, iy, g, buf, 256)
         return buf.value.decode() if n > 0 else None
 
-    def blend_changed(self, cap=4096):
+    def blend_changed(self, cap=4096, out=None):
+        """draw()'s texture refresh: ([(ix, iy)...], n x 256 x 256 x 3 uint8).  out: a caller-owned buffer of at least cap tiles
+        (e.g. host_array(): page-locked, filled straight from HBM)."""
         xy = (C.c_int * (2 * cap))()
-        out = np.empty((cap, ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
+        if out is None:
+            out = np.empty((cap, ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
         n = lib().pf_blend_changed(self._h, xy, out.ctypes.data, cap)
         return [(xy[2 * i], xy[2 * i + 1]) for i in range(n)], out[:n]
+
+    def blend_tiles(self, tiles, out=None):
+        """Ele::blend + 8U view of the listed tiles (Ischanged untouched); tiles without pyramid keep out's bytes."""
+        n = len(tiles)
+        xy = (C.c_int * (2 * n))(*[v for t in tiles for v in t])
+        if out is None:
+            out = np.zeros((n, ELE_PIXELS, ELE_PIXELS, 3), np.uint8)
+        return out[:n] if lib().pf_blend_tiles(self._h, xy, n, out.ctypes.data) else None
 
     # ---- multi-GPU seam exchange
     def halo_bytes(self, dx, dy):

@@ -171,6 +171,20 @@ int pf_get_tile_bgra(pf_map* m, int ix, int iy, uint8_t* bgra) { return m && bgr
 int pf_blend_tile_raw(pf_map* m, int ix, int iy, void* out) { return m && out && m->impl.blend_tile(ix, iy, out, nullptr, nullptr); }
 int pf_blend_tile(pf_map* m, int ix, int iy, uint8_t* bgr) { return m && bgr && m->impl.blend_tile(ix, iy, nullptr, bgr, nullptr); }
 int pf_blend_changed(pf_map* m, int* xy, uint8_t* bgr, int cap) { return (m && xy && bgr && cap > 0) ? m->impl.blend_changed(xy, bgr, cap) : 0; }
+int pf_blend_tiles(pf_map* m, const int* xy, int n, uint8_t* bgr)
+{
+    if (!m || !xy || !bgr || n <= 0) return 0;
+    std::vector<std::pair<int, int>> tiles(n);
+    for (int i = 0; i < n; i++) tiles[i] = { xy[2 * i], xy[2 * i + 1] };
+    return m->impl.blend_list(tiles, bgr);
+}
+void* pf_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void pf_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 // MultiBandMap2DCPUEle::normalizeUsingWeightMap / mulWeightMap (.cpp:57-75): no caller in
 // the reference; host loops kept for API completeness.

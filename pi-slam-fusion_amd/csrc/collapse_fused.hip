@@ -5,20 +5,25 @@
 //   save              :806-840                        paste per level, one whole-mosaic collapse, 8U, background
 //
 // Rounds 1-5 ran this as the reference writes it -- a padded square per level in HBM (k_blend_gather), one k_collapse launch
-// per level, a finish launch: 12 launches per chunk and every level through HBM twice.  Here a workgroup owns a 64 x 64
-// block of the level-0 result and collapses the part of the pyramid that block depends on inside LDS:
+// per level, a finish launch: 12 launches per chunk and every level through HBM twice.  Here a workgroup owns a 128 x 32
+// block of the level-0 result (a row segment of 384 bytes of BGR8 = three whole cache lines) and collapses the part of the
+// pyramid that block depends on inside LDS:
 //
 //   pyrUp is a 3-tap filter, so level i-1 rows [lo, hi] need level i rows [(lo-1)>>1, (hi>>1)+1]: one pixel of halo per
-//   level (34^2, 19^2, 12^2, 8^2, 6^2, 5^2 ... pixels for levels 1, 2, ...: 22 KB of LDS for any band count).
+//   level (66 x 18, 35 x 11, 20 x 8, 12 x 6, 8 x 5 ... pixels for levels 1, 2, ...: 23 KB of LDS for any band count).
 //   1. the Laplacian regions of levels 1..L go from the tile slots / packed halo strips / mosaic tiles straight into LDS;
-//   2. level L-1 ... 1 are restored in place in LDS (pyrUp + add, the reference's operation order, C-cast and saturation,
-//      and the borders of the padded square / the mosaic -- the edge forms of pyrUp are not index reflections in fp32);
+//   2. levels L-1 ... 1 are restored in place in LDS, one thread per 2 x 2 destination quad (pyrUp + add in the reference's
+//      operation order, with its C cast and saturation and the borders of the padded square / the mosaic -- the edge forms
+//      of pyrUp are not index reflections in fp32);
 //   3. level 0: a thread takes 2 rows x 4 columns, reads its 3 x 4 neighbourhood of level 1 from LDS once, adds the tile's
 //      own Laplacian (16-byte loads), applies the weight mask and the 8U view and writes 12 bytes per row.
 // Nothing of a level >= 1 ever returns to HBM, level 0 is read once and the result written once.
 //
-// Bit-exactness: compiled with -ffp-contract=off; every sum below is written in the association order of
-// OpenCV 2.4.9's pyrUp_ and checked against the oracle by the blend / save / dist tests.
+// Bit-exactness: compiled with -ffp-contract=off; every sum below is written in the association order of OpenCV 2.4.9's
+// pyrUp_.  One rewriting is used: pyrUp's odd-column sum (s[x] + s[x+1]) * 4 is carried as O = s[x] + s[x+1]
+// and the factor 4 folded into the final cast -- multiplying by a power of two commutes with fp32 rounding (no overflow or
+// underflow is reachable: the operands are sums of pixel values), and for 16S ((4 v + 32) >> 6) == ((v + 8) >> 4) exactly.
+// Checked against the oracle by the blend / save / dist tests and against the per-level kernels of rounds 1-5 (experiments library).
 #include "kernels.hpp"
 #include "warp_index.hpp"
 
@@ -27,63 +32,73 @@ namespace {
 
 #define PF_GLOBAL __attribute__((address_space(1)))
 
-constexpr int kCB = 64;                               // level-0 block edge of a workgroup
+constexpr int kBW = 128, kBH = 32;                    // level-0 block of a workgroup
 constexpr int kCT = 256;                              // threads
-constexpr int region_edge(int level) { int s = kCB; for (int i = 0; i < level; i++) s = ((s + 1) >> 1) + 2; return s; }
-constexpr int region_px_total() { int n = 0; for (int i = 1; i < kMaxLevels; i++) n += region_edge(i) * region_edge(i); return n; }
-constexpr int kLdsPx = region_px_total();             // 1836 pixels = 22 032 B of 3 x 4-byte components
-static_assert(region_edge(1) == 34 && region_edge(2) == 19 && region_edge(3) == 12, "pyrUp dependence regions");
+#ifndef PF_CF_WAVES
+#define PF_CF_WAVES 5
+#endif
+constexpr int kCFWaves = PF_CF_WAVES;                 // waves per SIMD the register budget is cut for (5: 96 VGPRs, five workgroups per CU; 6 spilled and was 30 % slower, profiles/r06_blend_ab.md)
+constexpr int region_edge(int s, int level) { for (int i = 0; i < level; i++) s = ((s + 1) >> 1) + 2; return s; }
+constexpr int region_px(int level) { return region_edge(kBW, level) * region_edge(kBH, level); }
+constexpr int region_px_total(int from) { int n = 0; for (int i = from; i < kMaxLevels; i++) n += region_px(i); return n; }
+constexpr int kLdsPx = region_px_total(1);            // 1925 pixels = 23 100 B of 3 x 4-byte components
+static_assert(region_edge(128, 1) == 66 && region_edge(32, 1) == 18 && region_edge(66, 1) == 35, "pyrUp dependence regions");
 
 typedef float    f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u3 __attribute__((ext_vector_type(3), aligned(4)));
 
 template <bool F32> struct Px;
 template <> struct Px<false> { using T = short; using WT = int; };
 template <> struct Px<true>  { using T = float; using WT = float; };
 
-__device__ __forceinline__ int   cast_up(int v)   { return (int)(short)((v + 32) >> 6); }      // (short) C cast: wraps
-__device__ __forceinline__ float cast_up(float v) { return v * (1.f / 64); }
+// pyrUp_'s vertical step + cast for the four parities of a destination pixel.  E = even-column horizontal sum, O = odd-column sum / 4
+// (see the header); rows 0 / 1 / 2 = source rows sy-1 / sy / sy+1.
+__device__ __forceinline__ int   up_ee(int e0, int e1, int e2)       { return (int)(short)((e0 + e1 * 6 + e2 + 32) >> 6); }   // (short) C cast: wraps
+__device__ __forceinline__ int   up_eo(int o0, int o1, int o2)       { return (int)(short)((o0 + o1 * 6 + o2 + 8) >> 4); }
+__device__ __forceinline__ int   up_oe(int e1, int e2)               { return (int)(short)((e1 + e2 + 8) >> 4); }
+__device__ __forceinline__ int   up_oo(int o1, int o2)               { return (int)(short)((o1 + o2 + 2) >> 2); }
+__device__ __forceinline__ float up_ee(float e0, float e1, float e2) { return (e0 + e1 * 6 + e2) * (1.f / 64); }
+__device__ __forceinline__ float up_eo(float o0, float o1, float o2) { return (o0 + o1 * 6 + o2) * (1.f / 16); }
+__device__ __forceinline__ float up_oe(float e1, float e2)           { return (e1 + e2) * (1.f / 16); }
+__device__ __forceinline__ float up_oo(float o1, float o2)           { return (o1 + o2) * (1.f / 4); }
 __device__ __forceinline__ int   add_sat(int up, int lap)     { return sat_short(up + lap); }  // cv::add on 16S saturates
 __device__ __forceinline__ float add_sat(float up, float lap) { return up + lap; }
 __device__ __forceinline__ uint32_t sat_u8(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-// region of a level held in LDS: rows [y0, y0 + h) x cols [x0, x0 + w) of the level's image (rows x cols), at lds[off ...]
-struct Reg { int y0, x0, h, w, off, rows, cols, lap_off; };
+// region of a level held in LDS: rows [y0, y0 + h) x cols [x0, x0 + w) of the level's image (rows x cols); the regions of levels
+// 1, 2, ... lie back to back, pixel p of the flat list at lds[3 p]
+struct Reg {
+    int y0, x0, h, w;
+    int poff, rows, cols;                // first pixel in the flat list; extent of the level's image
+};
+// what the flat loader needs of it, per level, in LDS
+struct RegL { int poff, y0, x0, w; float rcp_w; int lap_off, pad0_, pad1_; };
 
 struct Shared {
-    Reg reg[kMaxLevels];
+    RegL reg[kMaxLevels];
     BlendJob job;
 };
 
-// horizontal pass of pyrUp_ for destination column x of a source row `row` (indexed by absolute source column, 3 components apart)
-template <typename WT>
-__device__ __forceinline__ WT up_h(const WT* row, int x, int scols)
+// the recurrence above from the level-0 block; every input is workgroup-uniform, so this is scalar code
+__device__ __forceinline__ Reg level_region(int level, int Y0, int X0, int rows0, int cols0)
 {
-    const int sx = x >> 1;
-    if (scols == 1) return row[0] * 8;
-    if (x & 1) {
-        if (sx == scols - 1) return row[sx * 3] * 8;
-        return (row[sx * 3] + row[(sx + 1) * 3]) * 4;
+    int ylo = Y0, yhi = Y0 + kBH - 1, xlo = X0, xhi = X0 + kBW - 1, poff = 0;
+    Reg r{};
+    for (int i = 1; i <= level; i++) {
+        const int rows = rows0 >> i, cols = cols0 >> i;
+        ylo = (ylo - 1) >> 1; if (ylo < 0) ylo = 0;
+        xlo = (xlo - 1) >> 1; if (xlo < 0) xlo = 0;
+        yhi = (yhi >> 1) + 1; if (yhi > rows - 1) yhi = rows - 1;
+        xhi = (xhi >> 1) + 1; if (xhi > cols - 1) xhi = cols - 1;
+        r.y0 = ylo; r.x0 = xlo; r.h = yhi - ylo + 1; r.w = xhi - xlo + 1; r.poff = poff; r.rows = rows; r.cols = cols;
+        poff += r.h * r.w;
     }
-    if (sx == 0) return row[0] * 6 + row[3] * 2;
-    if (sx == scols - 1) return row[(sx - 1) * 3] + row[sx * 3] * 7;
-    return row[(sx - 1) * 3] + row[sx * 3] * 6 + row[(sx + 1) * 3];
+    return r;
 }
 
-// pyrUp(level i)[y][x][k] from the level's LDS region (reg = level i's)
-template <typename WT>
-__device__ __forceinline__ WT up_at(const WT* lds, const Reg& r, int y, int x, int k)
-{
-    const int sy = y >> 1;
-    const WT* base = lds + r.off + k - (r.y0 * r.w + r.x0) * 3;      // [sy * w * 3 + sx * 3] is the absolute pixel
-    int syn = sy + 1; if (syn >= r.rows) syn = r.rows - 1;
-    const WT* r1 = base + sy * r.w * 3;
-    const WT* r2 = base + syn * r.w * 3;
-    if (y & 1) return cast_up((up_h<WT>(r1, x, r.cols) + up_h<WT>(r2, x, r.cols)) * 4);
-    int syp = sy - 1; if (syp < 0) syp = r.rows > 1 ? 1 : 0;
-    const WT* r0 = base + syp * r.w * 3;
-    return cast_up(up_h<WT>(r0, x, r.cols) + up_h<WT>(r1, x, r.cols) * 6 + up_h<WT>(r2, x, r.cols));
-}
+// idx / w for 0 <= idx < 4096, 1 <= w <= 128, rcp = 1.f / w: (idx + 0.5) / w is at least 1 / 256 away from an integer, the float error is below 2^-10
+__device__ __forceinline__ int div_small(int idx, float rcp) { return (int)(((float)idx + 0.5f) * rcp); }
 
 __device__ __forceinline__ void strip_dims_d(int nlev, int level, int dx, int dy, int& w, int& h)
 {
@@ -159,13 +174,13 @@ template <> struct Row4<false> {
     }
 };
 
-// One workgroup = one 64 x 64 block of a level-0 result.
+// One workgroup = one 128 x 32 block of a level-0 result.
 //   MOSAIC = false: block (blockIdx % 16) of tile job[blockIdx / 16] (Ele::blend); results to raw / bgr at tile index job.out
-//   MOSAIC = true : block of the wx*4 x wy*4 block grid of the pasted mosaic (save); result to bgr (rows x cols x 3)
+//   MOSAIC = true : block of the wx*2 x wy*8 block grid of the pasted mosaic (save); result to bgr (rows x cols x 3)
 // Workgroup ids are dealt so that the blocks of one tile / of neighbouring tiles run on one XCD (they share the upper levels in its L2).
 template <bool F32, bool MOSAIC>
-__global__ __launch_bounds__(kCT) void k_collapse_fused(TileLayout lay, const BlendJob* __restrict__ jobs, const uint64_t* __restrict__ table,
-                                                         int wx, int wy, int bg, char* __restrict__ raw, uint8_t* __restrict__ bgr, int nblocks)
+__global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay, const BlendJob* __restrict__ jobs, const uint64_t* __restrict__ table,
+                                                                   int wx, int wy, int bg, char* __restrict__ raw, uint8_t* __restrict__ bgr, int nblocks)
 {
     using T = typename Px<F32>::T; using WT = typename Px<F32>::WT;
     __shared__ WT lds[kLdsPx * 3];
@@ -180,80 +195,154 @@ __global__ __launch_bounds__(kCT) void k_collapse_fused(TileLayout lay, const Bl
     int ly0, lx0;                                      // block origin inside that tile
     int out_tile = 0;
     if constexpr (MOSAIC) {
-        const int bx = wg % (wx * 4), by = wg / (wx * 4);
-        Y0 = by * kCB; X0 = bx * kCB; rows0 = wy * kElePixels; cols0 = wx * kElePixels;
+        const int nbx = wx * (kElePixels / kBW);
+        const int by = wg / nbx, bx = wg - by * nbx;
+        Y0 = by * kBH; X0 = bx * kBW; rows0 = wy * kElePixels; cols0 = wx * kElePixels;
         self = (const PF_GLOBAL char*)table[(Y0 >> 8) * wx + (X0 >> 8)];
         ly0 = Y0 & 255; lx0 = X0 & 255;
         if (!self) {                                   // no tile here: background (.cpp:840, weights never pasted stay 0)
             const uint32_t b8 = sat_u8(bg), word = b8 * 0x01010101u;
-            for (int t = tid; t < kCB * (kCB * 3 / 4); t += kCT) {
-                const int r = t / (kCB * 3 / 4), c = t - r * (kCB * 3 / 4);
+            constexpr int kRowWords = kBW * 3 / 4;
+            for (int t = tid; t < kBH * kRowWords; t += kCT) {
+                const int r = t / kRowWords, c = t - r * kRowWords;
                 ((uint32_t*)(bgr + ((size_t)(Y0 + r) * cols0 + X0) * 3))[c] = word;
             }
             return;
         }
     } else {
-        const int z = wg >> 4, blk = wg & 15;
+        constexpr int kPerTile = (kElePixels / kBW) * (kElePixels / kBH);
+        const int z = wg / kPerTile, blk = wg - z * kPerTile;
         if (tid < (int)(sizeof(BlendJob) / 4)) ((uint32_t*)&sh.job)[tid] = ((const uint32_t*)(jobs + z))[tid];
         const int b0 = jobs[z].border ? 1 << L : 0;
-        ly0 = (blk >> 2) * kCB; lx0 = (blk & 3) * kCB;
+        ly0 = (blk / (kElePixels / kBW)) * kBH; lx0 = (blk % (kElePixels / kBW)) * kBW;
         Y0 = b0 + ly0; X0 = b0 + lx0; rows0 = cols0 = kElePixels + 2 * b0;
         self = (const PF_GLOBAL char*)jobs[z].src[4];
         out_tile = jobs[z].out;
     }
 
-    // ---- regions of levels 1..L this block depends on
-    if (tid == 0) {
-        int ylo = Y0, yhi = Y0 + kCB - 1, xlo = X0, xhi = X0 + kCB - 1, off = 0;
-        for (int i = 1; i <= L; i++) {
-            const int rows = rows0 >> i, cols = cols0 >> i;
-            ylo = (ylo - 1) >> 1; if (ylo < 0) ylo = 0;
-            xlo = (xlo - 1) >> 1; if (xlo < 0) xlo = 0;
-            yhi = (yhi >> 1) + 1; if (yhi > rows - 1) yhi = rows - 1;
-            xhi = (xhi >> 1) + 1; if (xhi > cols - 1) xhi = cols - 1;
-            Reg r; r.y0 = ylo; r.x0 = xlo; r.h = yhi - ylo + 1; r.w = xhi - xlo + 1; r.off = off; r.rows = rows; r.cols = cols; r.lap_off = (int)lay.lap_off[i];
-            sh.reg[i] = r;
-            off += r.h * r.w * 3;
-        }
+    // ---- regions of levels 1..L this block depends on (thread i: level i, for the flat loader)
+    if (tid >= 1 && tid <= L) {
+        const Reg r = level_region(tid, Y0, X0, rows0, cols0);
+        RegL q; q.poff = r.poff; q.y0 = r.y0; q.x0 = r.x0; q.w = r.w; q.rcp_w = 1.f / (float)r.w; q.lap_off = (int)lay.lap_off[tid]; q.pad0_ = q.pad1_ = 0;
+        sh.reg[tid] = q;
     }
+    const Reg r1 = L >= 1 ? level_region(1, Y0, X0, rows0, cols0) : Reg{};
+    const Reg rL = L >= 1 ? level_region(L, Y0, X0, rows0, cols0) : Reg{};
+    const int total = L >= 1 ? rL.poff + rL.h * rL.w : 0;
     __syncthreads();
 
-    // ---- 1. Laplacian regions of levels 1..L -> LDS
-    for (int i = 1; i <= L; i++) {
-        const Reg r = sh.reg[i];
-        const int n = r.h * r.w;
-        for (int idx = tid; idx < n; idx += kCT) {
-            const int ry = idx / r.w, rx = idx - ry * r.w;
-            WT v[3];
-            if constexpr (MOSAIC) fetch_mosaic<F32>(table, wx, i, r.lap_off, r.y0 + ry, r.x0 + rx, v);
-            else fetch_blend<F32>(sh.job, lay.nlev, i, r.lap_off, r.y0 + ry, r.x0 + rx, v);
-            WT* d = lds + r.off + idx * 3;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2];
-        }
-    }
-    __syncthreads();
-
-    // ---- 2. restore levels L-1 .. 1 in place: pyr[i-1] = pyrUp(pyr[i]) + pyr[i-1]
-    for (int i = L; i >= 2; i--) {
-        const Reg rs = sh.reg[i], rd = sh.reg[i - 1];
-        const int n = rd.h * rd.w;
-        for (int idx = tid; idx < n; idx += kCT) {
-            const int ry = idx / rd.w, rx = idx - ry * rd.w;
-            WT* d = lds + rd.off + idx * 3;
+    // ---- 1. Laplacian regions of levels 1..L -> LDS; the loads of a thread are issued in batches before their LDS stores
+    if (L >= 1) {
+        // level 1 (three in five of the pixels): its region is workgroup-uniform, the index arithmetic scalar
+        constexpr int kIts1 = (region_px(1) + kCT - 1) / kCT;                 // 5
+        const int n1 = r1.h * r1.w, lap1 = (int)lay.lap_off[1];
+        const float rcp1 = 1.f / (float)r1.w;
+        WT v[kIts1][3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) d[k] = add_sat(up_at<WT>(lds, rs, rd.y0 + ry, rd.x0 + rx, k), d[k]);
+        for (int it = 0; it < kIts1; it++) {
+            const int idx = tid + it * kCT;
+            v[it][0] = v[it][1] = v[it][2] = (WT)0;
+            if (idx < n1) {
+                const int ry = div_small(idx, rcp1), rx = idx - ry * r1.w;
+                if constexpr (MOSAIC) fetch_mosaic<F32>(table, wx, 1, lap1, r1.y0 + ry, r1.x0 + rx, v[it]);
+                else fetch_blend<F32>(sh.job, lay.nlev, 1, lap1, r1.y0 + ry, r1.x0 + rx, v[it]);
+            }
+        }
+        // levels 2..L: the flat list dealt over the threads
+        constexpr int kIts2 = (region_px_total(2) + kCT - 1) / kCT;           // 3
+        WT u[kIts2][3];
+#pragma unroll
+        for (int it = 0; it < kIts2; it++) {
+            const int idx = n1 + tid + it * kCT;
+            u[it][0] = u[it][1] = u[it][2] = (WT)0;
+            if (idx < total) {
+                int lv = 2;
+#pragma unroll
+                for (int i = 3; i < kMaxLevels; i++) lv += (i <= L && idx >= sh.reg[i].poff) ? 1 : 0;
+                const RegL r = sh.reg[lv];
+                const int loc = idx - r.poff, ry = div_small(loc, r.rcp_w), rx = loc - ry * r.w;
+                if constexpr (MOSAIC) fetch_mosaic<F32>(table, wx, lv, r.lap_off, r.y0 + ry, r.x0 + rx, u[it]);
+                else fetch_blend<F32>(sh.job, lay.nlev, lv, r.lap_off, r.y0 + ry, r.x0 + rx, u[it]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kIts1; it++) {
+            const int idx = tid + it * kCT;
+            if (idx < n1) { lds[idx * 3] = v[it][0]; lds[idx * 3 + 1] = v[it][1]; lds[idx * 3 + 2] = v[it][2]; }
+        }
+#pragma unroll
+        for (int it = 0; it < kIts2; it++) {
+            const int idx = n1 + tid + it * kCT;
+            if (idx < total) { lds[idx * 3] = u[it][0]; lds[idx * 3 + 1] = u[it][1]; lds[idx * 3 + 2] = u[it][2]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. restore levels L-1 .. 1 in place: pyr[i-1] = pyrUp(pyr[i]) + pyr[i-1], one thread per 2 x 2 destination quad
+    // (quads aligned to even coordinates; a quad on the rim of the region has pixels outside it, which are not stored)
+    for (int i = L; i >= 2; i--) {
+        const Reg rs = level_region(i, Y0, X0, rows0, cols0), rd = level_region(i - 1, Y0, X0, rows0, cols0);
+        const WT* src = lds + rs.poff * 3 - (rs.y0 * rs.w + rs.x0) * 3;          // [(y * w + x) * 3] = source pixel (y, x)
+        WT* dst = lds + rd.poff * 3 - (rd.y0 * rd.w + rd.x0) * 3;
+        const int qy0 = rd.y0 >> 1, qx0 = rd.x0 >> 1, qw = ((rd.x0 + rd.w - 1) >> 1) - qx0 + 1, nq = (((rd.y0 + rd.h - 1) >> 1) - qy0 + 1) * qw;
+        const float rcp_qw = 1.f / (float)qw;
+        const int ylo = rs.y0, yhi = rs.y0 + rs.h - 1, xlo = rs.x0, xhi = rs.x0 + rs.w - 1;
+        for (int qi = tid; qi < nq; qi += kCT) {
+            const int qy = div_small(qi, rcp_qw), qx = qi - qy * qw;
+            const int sy = qy0 + qy, sx = qx0 + qx;
+            // source rows sy - 1, sy, sy + 1 with pyrUp's row rule (-1 -> 1, rows -> rows - 1), then clamped into the region: a row the region
+            // lacks is only ever asked for by a destination pixel outside the destination region
+            int r0 = sy - 1; if (r0 < 0) r0 = rs.rows > 1 ? 1 : 0;
+            int r2 = sy + 1; if (r2 > rs.rows - 1) r2 = rs.rows - 1;
+            r0 = r0 < ylo ? ylo : (r0 > yhi ? yhi : r0); r2 = r2 > yhi ? yhi : r2;
+            const int r1y = sy > yhi ? yhi : sy;
+            int ca = sx - 1; ca = ca < xlo ? xlo : ca;
+            int cc = sx + 1; cc = cc > xhi ? xhi : cc;
+            const int cb = sx > xhi ? xhi : sx;
+            const int rowo[3] = { r0 * rs.w * 3, r1y * rs.w * 3, r2 * rs.w * 3 };
+            WT E[3][3], O[3][3];
+            if (sx > 0 && sx < rs.cols - 1) {
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const WT a = src[rowo[rr] + ca * 3 + k], b = src[rowo[rr] + cb * 3 + k], c = src[rowo[rr] + cc * 3 + k];
+                        E[rr][k] = a + b * 6 + c; O[rr][k] = b + c;
+                    }
+            } else {
+                const bool single = rs.cols == 1, left = sx == 0;
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const WT a = src[rowo[rr] + ca * 3 + k], b = src[rowo[rr] + cb * 3 + k], c = src[rowo[rr] + cc * 3 + k];
+                        if (single)    { E[rr][k] = b * 8; O[rr][k] = b * 2; }
+                        else if (left) { E[rr][k] = b * 6 + c * 2; O[rr][k] = b + c; }
+                        else           { E[rr][k] = a + b * 7; O[rr][k] = b * 2; }      // right edge
+                    }
+            }
+            const int y = 2 * sy, x = 2 * sx;
+            const bool vy0 = y >= rd.y0, vy1 = y + 1 < rd.y0 + rd.h, vx0 = x >= rd.x0, vx1 = x + 1 < rd.x0 + rd.w;
+            WT* d0 = dst + (y * rd.w + x) * 3;
+            WT* d1 = d0 + rd.w * 3;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (vy0 && vx0) d0[k] = add_sat(up_ee(E[0][k], E[1][k], E[2][k]), d0[k]);
+                if (vy0 && vx1) d0[3 + k] = add_sat(up_eo(O[0][k], O[1][k], O[2][k]), d0[3 + k]);
+                if (vy1 && vx0) d1[k] = add_sat(up_oe(E[1][k], E[2][k]), d1[k]);
+                if (vy1 && vx1) d1[3 + k] = add_sat(up_oo(O[1][k], O[2][k]), d1[3 + k]);
+            }
         }
         __syncthreads();
     }
 
-    // ---- 3. level 0: 2 rows x 4 columns per thread, two passes over the block
+    // ---- 3. level 0: 2 rows x 4 columns per thread
     const PF_GLOBAL T* lap0 = (const PF_GLOBAL T*)(self + lay.lap_off[0]);
     const PF_GLOBAL float* w0 = (const PF_GLOBAL float*)(self + lay.w_off[0]);
-    Reg r1{};
-    if (L >= 1) r1 = sh.reg[1];
+    const WT* base1 = lds + r1.poff * 3 - (r1.y0 * r1.w + r1.x0) * 3;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const int t = tid + pass * kCT, q = t & 15, rp = t >> 4;
+    for (int pass = 0; pass < (kBH / 2) * (kBW / 4) / kCT; pass++) {
+        const int t = tid + pass * kCT, q = t % (kBW / 4), rp = t / (kBW / 4);
         const int ty = ly0 + 2 * rp, tx = lx0 + 4 * q;                     // inside the tile
         Row4<F32> px[2];
         f4 wv[2];
@@ -269,27 +358,29 @@ __global__ __launch_bounds__(kCT) void k_collapse_fused(TileLayout lay, const Bl
             int syn = sy + 1; if (syn >= r1.rows) syn = r1.rows - 1;
             const bool left = sx == 0, right = sx + 1 == r1.cols - 1;
             const int ca = left ? sx : sx - 1, cd = right ? sx + 1 : sx + 2;   // clamped column indices (values unused at the edges)
-            const WT* base = lds + r1.off - (r1.y0 * r1.w + r1.x0) * 3;
-            const int rowi[3] = { syp, sy, syn };
-            WT h[3][12];                                                   // horizontal sums of the three source rows, 4 columns x 3 components
+            const int rowo[3] = { syp * r1.w * 3, sy * r1.w * 3, syn * r1.w * 3 };
+            // per component: the three source rows' horizontal sums of the two quads, then the eight results
 #pragma unroll
-            for (int rr = 0; rr < 3; rr++) {
-                const WT* row = base + rowi[rr] * r1.w * 3;
+            for (int k = 0; k < 3; k++) {
+                WT E0[3], O0[3], E1[3], O1[3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const WT a = row[ca * 3 + k], b = row[sx * 3 + k], c = row[(sx + 1) * 3 + k], d = row[cd * 3 + k];
-                    h[rr][k]     = left ? b * 6 + c * 2 : a + b * 6 + c;
-                    h[rr][3 + k] = (b + c) * 4;
-                    h[rr][6 + k] = right ? b + c * 7 : b + c * 6 + d;
-                    h[rr][9 + k] = right ? c * 8 : (c + d) * 4;
+                for (int rr = 0; rr < 3; rr++) {
+                    const WT* row = base1 + rowo[rr] + k;
+                    const WT a = row[ca * 3], b = row[sx * 3], c = row[(sx + 1) * 3], d = row[cd * 3];
+                    if (!(left || right)) { E0[rr] = a + b * 6 + c; O0[rr] = b + c; E1[rr] = b + c * 6 + d; O1[rr] = c + d; }
+                    else {
+                        E0[rr] = left ? b * 6 + c * 2 : a + b * 6 + c; O0[rr] = b + c;
+                        E1[rr] = right ? b + c * 7 : b + c * 6 + d;    O1[rr] = right ? c * 2 : c + d;
+                    }
                 }
-            }
-#pragma unroll
-            for (int e = 0; e < 12; e++) {
-                const WT up0 = cast_up(h[0][e] + h[1][e] * 6 + h[2][e]);
-                const WT up1 = cast_up((h[1][e] + h[2][e]) * 4);
-                px[0].v[e] = add_sat(up0, px[0].v[e]);
-                px[1].v[e] = add_sat(up1, px[1].v[e]);
+                px[0].v[k]     = add_sat(up_ee(E0[0], E0[1], E0[2]), px[0].v[k]);
+                px[0].v[3 + k] = add_sat(up_eo(O0[0], O0[1], O0[2]), px[0].v[3 + k]);
+                px[0].v[6 + k] = add_sat(up_ee(E1[0], E1[1], E1[2]), px[0].v[6 + k]);
+                px[0].v[9 + k] = add_sat(up_eo(O1[0], O1[1], O1[2]), px[0].v[9 + k]);
+                px[1].v[k]     = add_sat(up_oe(E0[1], E0[2]), px[1].v[k]);
+                px[1].v[3 + k] = add_sat(up_oo(O0[1], O0[2]), px[1].v[3 + k]);
+                px[1].v[6 + k] = add_sat(up_oe(E1[1], E1[2]), px[1].v[6 + k]);
+                px[1].v[9 + k] = add_sat(up_oo(O1[1], O1[2]), px[1].v[9 + k]);
             }
         }
         // mask, 8U view, stores
@@ -316,12 +407,9 @@ __global__ __launch_bounds__(kCT) void k_collapse_fused(TileLayout lay, const Bl
             size_t o;                                                     // pixel index of the row's first output pixel
             if constexpr (MOSAIC) o = (size_t)(Y0 + 2 * rp + r) * cols0 + X0 + 4 * q;
             else o = (size_t)out_tile * (kElePixels * kElePixels) + (ty + r) * kElePixels + tx;
-            if (bgr) {
-                uint32_t* d = (uint32_t*)(bgr + o * 3);
-                d[0] = b8[0] | (b8[1] << 8) | (b8[2] << 16) | (b8[3] << 24);
-                d[1] = b8[4] | (b8[5] << 8) | (b8[6] << 16) | (b8[7] << 24);
-                d[2] = b8[8] | (b8[9] << 8) | (b8[10] << 16) | (b8[11] << 24);
-            }
+            if (bgr)
+                *(u3*)(bgr + o * 3) = u3{ b8[0] | (b8[1] << 8) | (b8[2] << 16) | (b8[3] << 24), b8[4] | (b8[5] << 8) | (b8[6] << 16) | (b8[7] << 24),
+                                          b8[8] | (b8[9] << 8) | (b8[10] << 16) | (b8[11] << 24) };
             if constexpr (!MOSAIC) { if (raw) px[r].store((T*)raw + o * 3); }
         }
     }
@@ -333,7 +421,7 @@ __global__ __launch_bounds__(kCT) void k_collapse_fused(TileLayout lay, const Bl
 void launch_blend_fused(hipStream_t s, const TileLayout& lay, const BlendJob* jobs_dev, int n, void* raw_out, uint8_t* bgr_out)
 {
     if (n <= 0) return;
-    const int nblocks = n * 16;
+    const int nblocks = n * (kElePixels / kBW) * (kElePixels / kBH);
     if (lay.f32) hipLaunchKernelGGL((k_collapse_fused<true, false>), dim3(nblocks), dim3(kCT), 0, s, lay, jobs_dev, (const uint64_t*)nullptr, 0, 0, 0, (char*)raw_out, bgr_out, nblocks);
     else         hipLaunchKernelGGL((k_collapse_fused<false, false>), dim3(nblocks), dim3(kCT), 0, s, lay, jobs_dev, (const uint64_t*)nullptr, 0, 0, 0, (char*)raw_out, bgr_out, nblocks);
 }
@@ -341,7 +429,7 @@ void launch_blend_fused(hipStream_t s, const TileLayout& lay, const BlendJob* jo
 // save(): the pasted wx x wy mosaic collapsed, 8U, background where no weight (table in device memory, 0 = no tile)
 void launch_save_fused(hipStream_t s, const TileLayout& lay, const uint64_t* table_dev, int wx, int wy, int bg, uint8_t* bgr_out)
 {
-    const int nblocks = wx * 4 * wy * 4;
+    const int nblocks = wx * (kElePixels / kBW) * wy * (kElePixels / kBH);
     if (nblocks <= 0) return;
     if (lay.f32) hipLaunchKernelGGL((k_collapse_fused<true, true>), dim3(nblocks), dim3(kCT), 0, s, lay, (const BlendJob*)nullptr, table_dev, wx, wy, bg, (char*)nullptr, bgr_out, nblocks);
     else         hipLaunchKernelGGL((k_collapse_fused<false, true>), dim3(nblocks), dim3(kCT), 0, s, lay, (const BlendJob*)nullptr, table_dev, wx, wy, bg, (char*)nullptr, bgr_out, nblocks);

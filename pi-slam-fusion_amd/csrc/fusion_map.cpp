@@ -1738,7 +1738,7 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
         }
         tile_bytes[nb] = b;
     }
-    constexpr size_t kBlendLaunch = 1024;         // tiles per launch: bounds the result buffers in HBM (fp32 raw: 805 MB)
+    constexpr size_t kBlendLaunch = 4096;         // tiles per launch: bounds the result buffers in HBM (BGR8: 805 MB; fp32 raw: 3.2 GB)
     for (size_t c0 = 0; c0 < tiles.size(); c0 += kBlendLaunch) {
         const size_t cn = std::min(kBlendLaunch, tiles.size() - c0);
         std::vector<BlendJob> jobs; jobs.reserve(cn);
@@ -1891,6 +1891,13 @@ bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* 
     if (!t || t->fresh) return false;
     std::vector<std::pair<int, int>> one{ { ix, iy } };
     return blend_batch(one, halo, raw, bgr);
+}
+
+bool FusionMap::blend_list(const std::vector<std::pair<int, int>>& tiles, uint8_t* bgr)
+{
+    std::lock_guard<std::mutex> l(mu_);
+    if (!init_ok_ || !set_device() || single_band_) return false;
+    return blend_batch(tiles, nullptr, nullptr, bgr);
 }
 
 // the draw() loop's texture refresh (.cpp:705-742) without GL

@@ -152,6 +152,7 @@ public:
     bool get_tile_bgra(int ix, int iy, uint8_t* bgra);
     bool blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* const* halo);
     int  blend_changed(int* xy, uint8_t* bgr, int cap);
+    bool blend_list(const std::vector<std::pair<int, int>>& tiles, uint8_t* bgr);      // pf_blend_tiles: Ischanged left alone
     size_t halo_bytes_for(int dx, int dy) const { return halo_bytes(lay_, dx, dy); }
     bool halo_pack(int ix, int iy, int dx, int dy, void* dev_out);
     size_t tile_bytes() const { return lay_.slot_bytes; }

@@ -37,6 +37,9 @@ def pipelined(name):
 def short(name):
     if pipelined(name):          # pipelined launch: level 0 of a frame + upper levels of earlier frames
         return "level0_fused"
+    m = re.search(r"k_collapse_fused<(\w+), (\w+)>", name)
+    if m:                        # the fused output-side kernel: Ele::blend (MOSAIC = false) / save (true)
+        return "save_fused" if m.group(2) == "true" else "blend_fused"
     m = re.search(r"k_level3?<(\w+), (\w+)", name)
     if m:
         return "level0_fused" if m.group(2) == "true" else "level_fused"
