@@ -92,7 +92,8 @@ def guarded(fn, *a, **kw):
 
 # the sources of the fusion kernels and of the host engine that builds their arguments (the files the PMC numbers depend on); the file
 # driver's image codecs (jpeg_decode.*, jpeg_device.*, image_io.cpp) are not among them
-KERNEL_SOURCES = ("dist.hpp", "fusion_map.hpp", "geometry.hpp", "kernels.hip", "kernels.hpp", "single_band.hip", "strips.inc", "warp_index.hpp")
+KERNEL_SOURCES = ("collapse_fused.hip", "dist.hpp", "fusion_map.cpp", "fusion_map.hpp", "geometry.hpp", "kernels.hip", "kernels.hpp", "single_band.hip",
+                  "strips.inc", "warp_index.hpp")
 
 
 def kernels_sha():
@@ -233,6 +234,55 @@ def host_feed_rate(pf, wl, poses, prep, frames_host, force_float, frames=60):
     return {"value": round(frames / dt, 1), "unit": "keyframes/s", "frames": frames,
             "h2d_GBps": round(nbytes * frames / dt / 1e9, 1),
             "note": "pageable host frames through pf_feed (36 MB H2D per keyframe inside feed)"}
+
+
+def output_side_rate(pf, wl, poses, prep, frames_dev, force_float, frames=60, reps=3):
+    """The output side of the path (SURVEY 3.1 hot loop #2): Ele::blend + the 8U view of EVERY tile of a mosaic of `frames` keyframes
+    (pf_blend_tiles: one launch of the fused collapse kernel) and save()'s whole-mosaic collapse (pf_save_to_memory).  `kernel_*`: the
+    launch by HIP events against the HBM roofline (algorithmic bytes: a tile's Laplacians and level-0 weights read once, the ring of
+    neighbour pixels the crop depends on, BGR8 written once); `wall_*`: with the device-to-host copy of the BGR8 result, into a
+    page-locked buffer (pf_host_alloc) and into a touched pageable one -- PCIe-bound, never `value`."""
+    import numpy as np
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float)
+    assert m.prepare(wl.IDENTITY_PLANE, CAM, prep)
+    for k in range(frames):
+        assert m.feed_device(frames_dev[k % len(frames_dev)].data_ptr(), CAM[1], CAM[0], pose_at(poses, k))
+    m.sync()
+    tiles = sorted(m.tiles())
+    n = len(tiles)
+    pinned = pf.host_array((n, 256, 256, 3)); plain = np.zeros((n, 256, 256, 3), np.uint8)
+    assert m.blend_tiles(tiles, out=pinned) is not None               # first launch: code object, result buffers, staging ring
+    def best(fn):
+        b = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); b = min(b, time.perf_counter() - t0)
+        return b
+    m.profile_reset(); m.profile_enable(1)
+    t_pin = best(lambda: m.blend_tiles(tiles, out=pinned))
+    pb = m.profile_read()["blend_fused"]; m.profile_reset()
+    t_page = best(lambda: m.blend_tiles(tiles, out=plain))
+    m.profile_reset()
+    img = m.save_to_memory(alloc=pf.host_array)
+    keep = img[0]
+    m.profile_reset()
+    t_save = best(lambda: m.save_to_memory(alloc=lambda shape: keep))
+    ps = m.profile_read()["save_fused"]
+    m.profile_enable(0)
+    same = bool(np.array_equal(pinned, plain))
+    m.close()
+    def kern(p):
+        ms = p["ms"] / max(p["launches"], 1)
+        g = p["alg_bytes"] / max(p["launches"], 1) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel_ms": round(ms, 4), "alg_bytes_per_launch": round(p["alg_bytes"] / max(p["launches"], 1)), "kernel_alg_GBps": round(g, 1),
+                "frac": round(g / HBM_PEAK_GBS, 4), "launches": p["launches"]}
+    out_b = n * 196608
+    return {"tiles": n, "mosaic_keyframes": frames, "kernel": "blend_fused", **kern(pb),
+            "kernel_tiles_per_s": round(n / (pb["ms"] / max(pb["launches"], 1) * 1e-3)) if pb["ms"] > 0 else None,
+            "wall_ms_pinned": round(t_pin * 1e3, 2), "tiles_per_s": round(n / t_pin), "d2h_GBps": round(out_b / t_pin / 1e9, 1),
+            "wall_ms_pageable": round(t_page * 1e3, 2), "tiles_per_s_pageable": round(n / t_page), "buffers_equal": same,
+            "save": {"kernel": "save_fused", "mosaic": [int(keep.shape[0]), int(keep.shape[1])], **kern(ps), "wall_ms_pinned": round(t_save * 1e3, 2),
+                     "d2h_GBps": round(keep.nbytes / t_save / 1e9, 1)},
+            "note": "Ele::blend + 8U view of every tile in one launch (collapse_fused.hip); wall = launch + D2H of n x 196 608 B (PCIe)"}
 
 
 def jpeg_feed_rate(pf, wl, poses, prep, force_float, frames=60):
@@ -387,9 +437,12 @@ def roofline_record(dom, p, dtype_key, event_every, pmc_ok=True, window=None):
            "avg_launch_us": round(us, 2), "alg_bytes_run_per_launch": round(run_bytes / launches),
            "alg_bytes_per_launch": round(p["alg_bytes"] / launches),
            "launches": p["launches"], "timed_every": event_every, "window": window}
+    rec["delivered_over_alg"] = None
     if pmc:
         if pmc.get("traffic") and us > 0:
             rec["frac_delivered"] = round(pmc["traffic"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            # HBM bytes moved per algorithmic byte processed: above 1 = re-reads / intermediates (the GW round trip, halo recompute)
+            rec["delivered_over_alg"] = round(pmc["traffic"] / max(run_bytes / launches, 1.0), 3)
         rec["pmc_build"] = {"git_sha": pmc.get("git_sha"), "kernels_sha": pmc.get("kernels_sha"), "current": pmc.get("current"),
                             "launches_averaged": pmc.get("launches")}
         if pmc.get("valu_insts") and us > 0:
@@ -677,6 +730,7 @@ def main():
             if N == 1:
                 out["host_feed"] = guarded(host_feed_rate, pf, wl, my_sortie, prep, hostf, force_float)
                 out["jpeg_feed"] = guarded(jpeg_feed_rate, pf, wl, my_sortie, prep, force_float)
+                out["blend"] = guarded(output_side_rate, pf, wl, my_sortie, prep, frames, force_float)
                 out["map2dcpu_single_band"] = guarded(map2dcpu_rates, pf, wl, my_sortie, prep, frames, hostf)
     if rank == 0:
         real_out.write(json.dumps(out) + "\n"); real_out.flush()

@@ -37,6 +37,9 @@ constexpr int kCT = 256;                              // threads
 #ifndef PF_CF_WAVES
 #define PF_CF_WAVES 5
 #endif
+#ifndef PF_CF_ABLATE         // timing-only A/B builds (tools/build_variant.sh): 1 no region loads, 2 no restore of levels L-1..1, 4 no level-1 sums in the level-0 pass
+#define PF_CF_ABLATE 0
+#endif
 constexpr int kCFWaves = PF_CF_WAVES;                 // waves per SIMD the register budget is cut for (5: 96 VGPRs, five workgroups per CU; 6 spilled and was 30 % slower, profiles/r06_blend_ab.md)
 constexpr int region_edge(int s, int level) { for (int i = 0; i < level; i++) s = ((s + 1) >> 1) + 2; return s; }
 constexpr int region_px(int level) { return region_edge(kBW, level) * region_edge(kBH, level); }
@@ -151,6 +154,7 @@ template <> struct Row4<true> {
         const f4 a = q[0], b = q[1], c = q[2];
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
     }
+    __device__ __forceinline__ float in(int e) const { return v[e]; }
     __device__ __forceinline__ void store(float* p) const {
         f4* q = (f4*)p;
         q[0] = f4{ v[0], v[1], v[2], v[3] }; q[1] = f4{ v[4], v[5], v[6], v[7] }; q[2] = f4{ v[8], v[9], v[10], v[11] };
@@ -158,19 +162,19 @@ template <> struct Row4<true> {
 };
 template <> struct Row4<false> {
     int v[12];
+    uint32_t u[6];                                                     // as loaded: unpacked where the values are first used (12 fewer live registers while the level-1 sums are formed)
     __device__ __forceinline__ void load(const PF_GLOBAL short* p) {
         const PF_GLOBAL u2* q = (const PF_GLOBAL u2*)p;                // 24 bytes, 8-byte aligned
         const u2 a = q[0], b = q[1], c = q[2];
-        const uint32_t u[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-#pragma unroll
-        for (int i = 0; i < 6; i++) { v[2 * i] = (int)(short)(u[i] & 0xffffu); v[2 * i + 1] = (int)(short)(u[i] >> 16); }
+        u[0] = a.x; u[1] = a.y; u[2] = b.x; u[3] = b.y; u[4] = c.x; u[5] = c.y;
     }
+    __device__ __forceinline__ int in(int e) const { return (e & 1) ? (int)u[e >> 1] >> 16 : (int)(short)(u[e >> 1] & 0xffffu); }
     __device__ __forceinline__ void store(short* p) const {
-        uint32_t u[6];
+        uint32_t w[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) u[i] = ((uint32_t)v[2 * i] & 0xffffu) | ((uint32_t)v[2 * i + 1] << 16);
+        for (int i = 0; i < 6; i++) w[i] = ((uint32_t)v[2 * i] & 0xffffu) | ((uint32_t)v[2 * i + 1] << 16);
         u2* q = (u2*)p;
-        q[0] = u2{ u[0], u[1] }; q[1] = u2{ u[2], u[3] }; q[2] = u2{ u[4], u[5] };
+        q[0] = u2{ w[0], w[1] }; q[1] = u2{ w[2], w[3] }; q[2] = u2{ w[4], w[5] };
     }
 };
 
@@ -231,8 +235,12 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
     const int total = L >= 1 ? rL.poff + rL.h * rL.w : 0;
     __syncthreads();
 
+    // Roles of phases 1 and 2 are dealt to the waves in an order that turns with the workgroup: the restore of the small top levels is
+    // work of the first wave(s) alone, and wave k of every workgroup lands on SIMD k
+    const int rt = (tid + 64 * ((blockIdx.x >> 3) & 3)) & (kCT - 1);
+
     // ---- 1. Laplacian regions of levels 1..L -> LDS; the loads of a thread are issued in batches before their LDS stores
-    if (L >= 1) {
+    if (L >= 1 && !(PF_CF_ABLATE & 1)) {
         // level 1 (three in five of the pixels): its region is workgroup-uniform, the index arithmetic scalar
         constexpr int kIts1 = (region_px(1) + kCT - 1) / kCT;                 // 5
         const int n1 = r1.h * r1.w, lap1 = (int)lay.lap_off[1];
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
         WT v[kIts1][3];
 #pragma unroll
         for (int it = 0; it < kIts1; it++) {
-            const int idx = tid + it * kCT;
+            const int idx = rt + it * kCT;
             v[it][0] = v[it][1] = v[it][2] = (WT)0;
             if (idx < n1) {
                 const int ry = div_small(idx, rcp1), rx = idx - ry * r1.w;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
         WT u[kIts2][3];
 #pragma unroll
         for (int it = 0; it < kIts2; it++) {
-            const int idx = n1 + tid + it * kCT;
+            const int idx = n1 + rt + it * kCT;
             u[it][0] = u[it][1] = u[it][2] = (WT)0;
             if (idx < total) {
                 int lv = 2;
@@ -267,12 +275,12 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
         }
 #pragma unroll
         for (int it = 0; it < kIts1; it++) {
-            const int idx = tid + it * kCT;
+            const int idx = rt + it * kCT;
             if (idx < n1) { lds[idx * 3] = v[it][0]; lds[idx * 3 + 1] = v[it][1]; lds[idx * 3 + 2] = v[it][2]; }
         }
 #pragma unroll
         for (int it = 0; it < kIts2; it++) {
-            const int idx = n1 + tid + it * kCT;
+            const int idx = n1 + rt + it * kCT;
             if (idx < total) { lds[idx * 3] = u[it][0]; lds[idx * 3 + 1] = u[it][1]; lds[idx * 3 + 2] = u[it][2]; }
         }
     }
@@ -280,14 +288,14 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
 
     // ---- 2. restore levels L-1 .. 1 in place: pyr[i-1] = pyrUp(pyr[i]) + pyr[i-1], one thread per 2 x 2 destination quad
     // (quads aligned to even coordinates; a quad on the rim of the region has pixels outside it, which are not stored)
-    for (int i = L; i >= 2; i--) {
+    for (int i = (PF_CF_ABLATE & 2) ? 1 : L; i >= 2; i--) {
         const Reg rs = level_region(i, Y0, X0, rows0, cols0), rd = level_region(i - 1, Y0, X0, rows0, cols0);
         const WT* src = lds + rs.poff * 3 - (rs.y0 * rs.w + rs.x0) * 3;          // [(y * w + x) * 3] = source pixel (y, x)
         WT* dst = lds + rd.poff * 3 - (rd.y0 * rd.w + rd.x0) * 3;
         const int qy0 = rd.y0 >> 1, qx0 = rd.x0 >> 1, qw = ((rd.x0 + rd.w - 1) >> 1) - qx0 + 1, nq = (((rd.y0 + rd.h - 1) >> 1) - qy0 + 1) * qw;
         const float rcp_qw = 1.f / (float)qw;
         const int ylo = rs.y0, yhi = rs.y0 + rs.h - 1, xlo = rs.x0, xhi = rs.x0 + rs.w - 1;
-        for (int qi = tid; qi < nq; qi += kCT) {
+        for (int qi = rt; qi < nq; qi += kCT) {
             const int qy = div_small(qi, rcp_qw), qx = qi - qy * qw;
             const int sy = qy0 + qy, sx = qx0 + qx;
             // source rows sy - 1, sy, sy + 1 with pyrUp's row rule (-1 -> 1, rows -> rows - 1), then clamped into the region: a row the region
@@ -344,14 +352,17 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
     for (int pass = 0; pass < (kBH / 2) * (kBW / 4) / kCT; pass++) {
         const int t = tid + pass * kCT, q = t % (kBW / 4), rp = t / (kBW / 4);
         const int ty = ly0 + 2 * rp, tx = lx0 + 4 * q;                     // inside the tile
+        // the weights first: their eight "== 0" bits are taken while the Laplacian loads are still in flight
         Row4<F32> px[2];
-        f4 wv[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            px[r].load(lap0 + ((ty + r) * kElePixels + tx) * 3);
-            wv[r] = *(const PF_GLOBAL f4*)(w0 + (ty + r) * kElePixels + tx);
+        unsigned zmask;
+        {
+            const f4 wa = *(const PF_GLOBAL f4*)(w0 + ty * kElePixels + tx), wb = *(const PF_GLOBAL f4*)(w0 + (ty + 1) * kElePixels + tx);
+            px[0].load(lap0 + (ty * kElePixels + tx) * 3);
+            px[1].load(lap0 + ((ty + 1) * kElePixels + tx) * 3);
+            zmask = (wa.x == 0.f ? 1u : 0u) | (wa.y == 0.f ? 2u : 0u) | (wa.z == 0.f ? 4u : 0u) | (wa.w == 0.f ? 8u : 0u) |
+                    (wb.x == 0.f ? 16u : 0u) | (wb.y == 0.f ? 32u : 0u) | (wb.z == 0.f ? 64u : 0u) | (wb.w == 0.f ? 128u : 0u);
         }
-        if (L >= 1) {
+        if (L >= 1 && !(PF_CF_ABLATE & 4)) {
             const int y = Y0 + 2 * rp, x = X0 + 4 * q;                     // in the padded level-0 image; both even, x % 4 == 0
             const int sy = y >> 1, sx = x >> 1;
             int syp = sy - 1; if (syp < 0) syp = r1.rows > 1 ? 1 : 0;
@@ -373,24 +384,27 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
                         E1[rr] = right ? b + c * 7 : b + c * 6 + d;    O1[rr] = right ? c * 2 : c + d;
                     }
                 }
-                px[0].v[k]     = add_sat(up_ee(E0[0], E0[1], E0[2]), px[0].v[k]);
-                px[0].v[3 + k] = add_sat(up_eo(O0[0], O0[1], O0[2]), px[0].v[3 + k]);
-                px[0].v[6 + k] = add_sat(up_ee(E1[0], E1[1], E1[2]), px[0].v[6 + k]);
-                px[0].v[9 + k] = add_sat(up_eo(O1[0], O1[1], O1[2]), px[0].v[9 + k]);
-                px[1].v[k]     = add_sat(up_oe(E0[1], E0[2]), px[1].v[k]);
-                px[1].v[3 + k] = add_sat(up_oo(O0[1], O0[2]), px[1].v[3 + k]);
-                px[1].v[6 + k] = add_sat(up_oe(E1[1], E1[2]), px[1].v[6 + k]);
-                px[1].v[9 + k] = add_sat(up_oo(O1[1], O1[2]), px[1].v[9 + k]);
+                px[0].v[k]     = add_sat(up_ee(E0[0], E0[1], E0[2]), px[0].in(k));
+                px[0].v[3 + k] = add_sat(up_eo(O0[0], O0[1], O0[2]), px[0].in(3 + k));
+                px[0].v[6 + k] = add_sat(up_ee(E1[0], E1[1], E1[2]), px[0].in(6 + k));
+                px[0].v[9 + k] = add_sat(up_eo(O1[0], O1[1], O1[2]), px[0].in(9 + k));
+                px[1].v[k]     = add_sat(up_oe(E0[1], E0[2]), px[1].in(k));
+                px[1].v[3 + k] = add_sat(up_oo(O0[1], O0[2]), px[1].in(3 + k));
+                px[1].v[6 + k] = add_sat(up_oe(E1[1], E1[2]), px[1].in(6 + k));
+                px[1].v[9 + k] = add_sat(up_oo(O1[1], O1[2]), px[1].in(9 + k));
             }
+        }
+        else {
+#pragma unroll
+            for (int e = 0; e < 12; e++) { px[0].v[e] = px[0].in(e); px[1].v[e] = px[1].in(e); }
         }
         // mask, 8U view, stores
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            const float wr[4] = { wv[r].x, wv[r].y, wv[r].z, wv[r].w };
             uint32_t b8[12];
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const bool zero = wr[p] == 0.f;
+                const bool zero = (zmask >> (4 * r + p)) & 1u;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const int e = p * 3 + k;

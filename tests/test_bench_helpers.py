@@ -91,3 +91,63 @@ def test_pmc_records_are_keyed_by_window(tmp_path, monkeypatch):
     r = bench.roofline_record("level0_fused", p, "f32", 4, True, "k20_w5_pre15")
     assert r["traffic"] == 400 and r["frac_delivered"] is not None and r["pmc_build"]["launches_averaged"] == 20
     assert bench.roofline_record("level0_fused", p, "f32", 4, True, "k20_w5_pre15_nocull")["traffic"] is None
+
+
+def test_delivered_over_alg_is_in_the_roofline_record(tmp_path, monkeypatch):
+    """The wasted-traffic ratio (PMC bytes moved per algorithmic byte processed) is part of the line, not only derivable from it
+    (VERDICT r05 item 5): 331.9 / 254.6 MB of round 5's driver window = 1.30."""
+    import json
+    d = tmp_path / "profiles"; d.mkdir()
+    (d / "pmc_traffic.json").write_text(json.dumps({
+        "_meta": {"git_sha": "x", "kernels_sha": "y"},
+        "f32": {"level0_fused": {"windows": {"k20_w5_pre15": {"traffic": 331900000, "launches": 20}}}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernels_sha", lambda: "y")
+    p = {"ms": 0.1076 * 20, "launches": 20, "alg_bytes": 4.2e8 * 20, "alg_bytes_run": 254.59e6 * 20}
+    r = bench.roofline_record("level0_fused", p, "f32", 4, True, "k20_w5_pre15")
+    assert abs(r["delivered_over_alg"] - 331.9 / 254.59) < 2e-3
+    assert bench.roofline_record("level0_fused", p, "f32", 4, False, "k20_w5_pre15")["delivered_over_alg"] is None
+
+
+def test_kernels_sha_covers_the_host_engine_and_the_collapse_kernel():
+    """The cull, the need bitmaps and the launch arguments are built in fusion_map.cpp: a change there changes the bytes a launch
+    touches, so the PMC numbers' build id must move with it."""
+    assert {"fusion_map.cpp", "collapse_fused.hip", "kernels.hip"} <= set(bench.KERNEL_SOURCES)
+
+
+def test_output_side_record_fields(monkeypatch):
+    """bench.output_side_rate against a stand-in package: the record's arithmetic (tiles/s, GB/s, roofline fraction of the launch)."""
+    import numpy as np
+    import types
+
+    class FakeMap:
+        def __init__(self): self.prof = {}
+        def prepare(self, *a): return True
+        def feed_device(self, *a): return True
+        def sync(self): return True
+        def tiles(self): return [(x, y) for y in range(4) for x in range(5)]
+        def profile_reset(self): self.prof = {}
+        def profile_enable(self, v): pass
+        def close(self): pass
+        def blend_tiles(self, tiles, out=None):
+            out[:] = 7
+            r = self.prof.setdefault("blend_fused", {"ms": 0.0, "launches": 0, "alg_bytes": 0.0})
+            r["ms"] += 0.01; r["launches"] += 1; r["alg_bytes"] += len(tiles) * 1.5e6
+            return out
+        def save_to_memory(self, alloc=None):
+            a = alloc((1024, 1280, 3))
+            r = self.prof.setdefault("save_fused", {"ms": 0.0, "launches": 0, "alg_bytes": 0.0})
+            r["ms"] += 0.02; r["launches"] += 1; r["alg_bytes"] += 4e7
+            return a, (0, 0)
+        def profile_read(self): return self.prof
+
+    fake = types.SimpleNamespace(TypeMultiBandCPU=3, host_array=lambda shape: np.zeros(shape, np.uint8),
+                                 Map2D=types.SimpleNamespace(create=lambda *a, **k: FakeMap()))
+    wl = types.SimpleNamespace(IDENTITY_PLANE=[0, 0, 0, 0, 0, 0, 1])
+    dev = [types.SimpleNamespace(data_ptr=lambda: 0)]
+    r = bench.output_side_rate(fake, wl, [[0, 0, -100, 0, 0, 0, 1]] * 4, None, dev, 1, frames=3, reps=2)
+    assert r["tiles"] == 20 and r["kernel"] == "blend_fused" and r["buffers_equal"] is True
+    assert r["kernel_ms"] == 0.01 and r["alg_bytes_per_launch"] == 30000000
+    assert abs(r["kernel_alg_GBps"] - 3000.0) < 1 and abs(r["frac"] - 3000.0 / bench.HBM_PEAK_GBS) < 1e-3
+    assert r["kernel_tiles_per_s"] == 2000000 and r["tiles_per_s"] > 0 and r["d2h_GBps"] > 0
+    assert r["save"]["kernel"] == "save_fused" and r["save"]["mosaic"] == [1024, 1280] and abs(r["save"]["kernel_alg_GBps"] - 2000.0) < 1
