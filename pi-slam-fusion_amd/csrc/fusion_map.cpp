@@ -1,6 +1,7 @@
 // fusion_map.cpp -- host engine: prepare / feed / renderFrame / blend / save on
 // the GPU, following the control flow of Map2DFusion/MultiBandMap2DCPU.cpp.
 #include "fusion_map.hpp"
+#include "env.hpp"
 #include "warp_index.hpp"
 #include <algorithm>
 #include <cmath>
@@ -31,10 +32,10 @@ int tile_owner(int shard_count, int shard_block, int ix, int iy)
 {
     if (shard_count <= 1) return 0;
     const int b = shard_block > 0 ? shard_block : 8;
-    // PF_SHARD_OWNER=cyclic (evaluation only, tools/predict_scaling.py --owner cyclic; every rank must set it alike): SURVEY 8e's other
+    // PF_SHARD_OWNER_CYCLIC=1 (experiments library; evaluation only, tools/predict_scaling.py --owner cyclic; every rank must set it alike): SURVEY 8e's other
     // candidate, a 2-D block-cyclic owner -- cells dealt over a px x py grid of ranks (px * py = shard_count, px the larger factor), so that
     // neighbouring cells never share a rank and any px x py window of cells holds every rank once
-    static const bool cyclic = std::getenv("PF_SHARD_OWNER") && std::string(std::getenv("PF_SHARD_OWNER")) == "cyclic";
+    static const bool cyclic = exp_env_int("PF_SHARD_OWNER_CYCLIC", 0) != 0;     // experiments library only
     if (cyclic) {
         int py = 1;
         for (int d = 1; d * d <= shard_count; d++) if (shard_count % d == 0) py = d;
@@ -176,7 +177,7 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     if (single_band_) { lay_.f32 = 0; lay_.lap_off[0] = 0; lay_.w_off[0] = 0; lay_.slot_bytes = kElePixels * kElePixels * 4; }
     store_.configure(lay_.slot_bytes);
     if (opt_.max_queue <= 0) opt_.max_queue = 20;
-    table_in_args_ = std::getenv("PF_TABLE_COPY") == nullptr;          // PF_TABLE_COPY=1: every tile table staged and copied in the stream (A/B, tests)
+    table_in_args_ = exp_env("PF_TABLE_COPY") == nullptr;              // experiments library, PF_TABLE_COPY=1: every tile table staged and copied in the stream (A/B, tests)
     if (opt_.shard_count < 1) opt_.shard_count = 1;
     if (opt_.shard_block < 1) opt_.shard_block = 8;
 
@@ -679,13 +680,74 @@ bool FusionMap::spread_map(double xmin, double ymin, double xmax, double ymax)
 }
 
 // ------------------------------------------------------------ renderFrame
+// MultiBandMap2DCPU::renderFrame (.cpp:311-558) in stages; FrameWork (fusion_map.hpp) is what one stage leaves for the next:
+//   frame_canvas        1-3  footprint, tile range, homography                         (.cpp:324-441)
+//   build_tile_table         Apply's tile loop: owned tiles, the cull, the table entries (.cpp:476-492)
+//   level_windows / plan_fused_levels   where each pyramid level is needed: windows, compute regions, need bitmaps and rectangles
+//   reserve_frame_workspace / place_table   grow-only buffers, the table's ring slot
+//   launch_fused_pipeline | launch_level_streams | launch_per_op | launch_single_band   the kernels (.cpp:443-555)
+//   retire_frame             flags, weight bounds, counters
+namespace {
+inline void clampw(int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); }
+// a box of level-0 pixels (multiples of 64) at level i: floor / ceil (at the top levels a cell is less than a pixel)
+inline int lv_lo(int p, int i) { return p >> i; }
+inline int lv_hi(int p, int i) { return (p + (1 << i) - 1) >> i; }
+}
+
 bool FusionMap::render_frame(const QueuedFrame& f)
 {
     Section sec(this, T_RENDER);
-    // 1. pose -> ground points (.cpp:324-347)
-    double pts[8];
-    if (!footprint(cam_, f.pose, pts)) { n_rejected_++; return false; }
-    // 2. destination (.cpp:349-394)
+    FrameWork& w = fw_;
+    w.reset();
+    const int go = frame_canvas(f, w);
+    if (go <= 0) { if (go < 0) n_rejected_++; return go == 0; }          // -1: rejected (.cpp:340-343, :381-386); 0: geometry-only frame
+    Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
+    if (!build_tile_table(f, w)) return false;
+    if (w.bx0 >= w.bx1) {                      // nothing of this frame lands on this shard, or it cannot win anywhere it lands
+        for (auto& r : w.raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
+        for (Tile* t : w.culled) t->changed = true;
+        if (w.owned_all) n_rendered_++;
+        log_rendered(f);
+        return true;
+    }
+    px_owned_ += (double)w.owned * kElePixels * kElePixels;     // what this rank renders beyond its share: owned tile pixels vs the level-0 window (bench --shard strong)
+    n_with_pixels_++;
+    level_windows(w);
+    if (!reserve_frame_workspace(w) || !place_table(w)) return false;
+    warp_args(f, w);
+    const bool fused = opt_.fused != 0 && w.L >= 1;
+    bool ok;
+    if (single_band_) ok = launch_single_band(f, w);
+    else if (fused) {
+        // weightImage (MultiBandMap2DCPU.cpp:396-425): built once per frame size, gathered by the warp
+        if (wmap_rows_ != f.rows || wmap_cols_ != f.cols) {
+            HIP_OK(sync_all());
+            if (!wmap_.reserve((size_t)f.rows * f.cols * 4)) return false;
+            launch_weight32(stream_, (float*)wmap_.p, f.rows, f.cols, opt_.weight_type);
+            wmap_rows_ = f.rows; wmap_cols_ = f.cols;
+        }
+        w.a.wmap = (const float*)wmap_.p;
+        plan_fused_levels(w);
+        ok = opt_.fused == 1 ? launch_fused_pipeline(f, w) : launch_level_streams(f, w);
+    } else ok = launch_per_op(f, w);
+    if (!ok) return false;
+    HIP_OK(hipGetLastError());
+    return retire_frame(f, w, fused);
+}
+
+void FusionMap::log_rendered(const QueuedFrame& f)
+{
+    if (f.seq < 0) return;
+    if (render_log_.size() >= 65536) render_log_.erase(render_log_.begin(), render_log_.begin() + 32768);
+    render_log_.push_back(f.seq);
+}
+
+// 1. pose -> ground points (.cpp:324-347); 2. destination tile range, spreadMap when the footprint leaves the grid (.cpp:349-394);
+// 3. homography (.cpp:427-441).  Returns 1 to go on, 0 for a geometry-only frame (other shards own its tiles), -1 rejected.
+int FusionMap::frame_canvas(const QueuedFrame& f, FrameWork& w)
+{
+    double* pts = w.pts;
+    if (!footprint(cam_, f.pose, pts)) return -1;
     double xmin = pts[0], xmax = xmin, ymin = pts[1], ymax = ymin;
     for (int i = 1; i < 4; i++) {
         if (pts[2 * i] < xmin) xmin = pts[2 * i];
@@ -694,98 +756,92 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         if (pts[2 * i + 1] > ymax) ymax = pts[2 * i + 1];
     }
     if (xmin < min_[0] || xmax > max_[0] || ymin < min_[1] || ymax > max_[1])
-        if (!spread_map(xmin, ymin, xmax, ymax)) { n_rejected_++; return false; }
-    const int xminInt = (int)std::floor((xmin - min_[0]) * ele_size_inv_);
-    const int yminInt = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
-    const int xmaxInt = (int)std::ceil((xmax - min_[0]) * ele_size_inv_);
-    const int ymaxInt = (int)std::ceil((ymax - min_[1]) * ele_size_inv_);
-    if (xminInt < 0 || yminInt < 0 || xmaxInt > w_ || ymaxInt > h_ || xminInt >= xmaxInt || yminInt >= ymaxInt) {
+        if (!spread_map(xmin, ymin, xmax, ymax)) return -1;
+    w.xminInt = (int)std::floor((xmin - min_[0]) * ele_size_inv_);
+    w.yminInt = (int)std::floor((ymin - min_[1]) * ele_size_inv_);
+    w.xmaxInt = (int)std::ceil((xmax - min_[0]) * ele_size_inv_);
+    w.ymaxInt = (int)std::ceil((ymax - min_[1]) * ele_size_inv_);
+    if (w.xminInt < 0 || w.yminInt < 0 || w.xmaxInt > w_ || w.ymaxInt > h_ || w.xminInt >= w.xmaxInt || w.yminInt >= w.ymaxInt) {
         std::fprintf(stderr, "MultiBandMap2DCPU::renderFrame:should never happen!\n");
-        n_rejected_++;
-        return false;
+        return -1;
     }
-    xmin = min_[0] + ele_size_ * xminInt;
-    ymin = min_[1] + ele_size_ * yminInt;
-    const uint8_t* src = f.ext ? f.ext : (f.slot >= 0 ? slots_[f.slot].dev : nullptr);
-    if (!src) return true;                      // geometry-only frame (other shards own its tiles)
-
-    // 3. homography (.cpp:427-441)
+    xmin = min_[0] + ele_size_ * w.xminInt;
+    ymin = min_[1] + ele_size_ * w.yminInt;
+    w.src = f.ext ? f.ext : (f.slot >= 0 ? slots_[f.slot].dev : nullptr);
+    if (!w.src) return 0;
     const float src4[8] = { 0.f, 0.f, (float)cam_.w, 0.f, 0.f, (float)cam_.h, (float)cam_.w, (float)cam_.h };
     float dst4[8];
     for (int i = 0; i < 4; i++) {
         dst4[2 * i]     = (float)((pts[2 * i] - xmin) * length_pixel_inv_);
         dst4[2 * i + 1] = (float)((pts[2 * i + 1] - ymin) * length_pixel_inv_);
     }
-    double M0[9];
-    perspective_transform(src4, dst4, M0);
+    perspective_transform(src4, dst4, w.M0);
+    w.tx = w.xmaxInt - w.xminInt; w.ty = w.ymaxInt - w.yminInt; w.L = band_num_;
+    w.crows = w.ty * kElePixels; w.ccols = w.tx * kElePixels;
+    return 1;
+}
 
-    const int tx = xmaxInt - xminInt, ty = ymaxInt - yminInt, L = band_num_;
-    const int crows = ty * kElePixels, ccols = tx * kElePixels;
-
-    // One pass over the canvas tiles (Apply's tile loop, .cpp:478-492): the tiles this shard owns, their bounding box,
-    // the hash cells they fall in (for the need rectangles below) and the table entries: slot address | fresh bit.
-    // The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
-    Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
-    const bool sharded = opt_.shard_count > 1;
-    // Cull (round 4): a cell of a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- a
-    // tile whose cells are all out keeps table entry 0, exactly as if another shard owned it, and the level-0 blocks' own need test / the
-    // need rectangles below shrink the grid to what the remaining cells depend on.  Nothing changes in what is stored: `if (srcW >= dstW)`
-    // (.cpp:521, :542) is false at every pixel of such a cell.  Sound because both sides are bounded from the geometry alone, with margins
-    // (cell_out):
-    //   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the cell dilated by the pyramid's
-    //                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
-    //   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
-    //                 dilated cell, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
-    //                 then S_i > W_i^f.  Tile::wlb[cell] = max over f of wmin_f.
-    // Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
-    double Minv[9];
-    const bool cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(M0, Minv) && cull_frame_ok(Minv, crows, ccols);
-    // The unit of the cull is a CELL of a tile (64 x 64 pixels, 16 per tile; PF_CULL_SUB=2: a quadrant), dilated by the pyramid's support
-    // radius 2^(L+1) - 2 pixels rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose cells are
-    // all out is left out of the launch; otherwise the cells that are out travel as flag bits of its table entry and the kernels do not
-    // look at their pixels (kernels.hip, cell_culled), which may have been computed from input nobody produced.
-    struct Raise { Tile* t; int q; float w; };
-    std::vector<Raise> raise;                                    // (cell, wmin of this keyframe): applied once the frame is in
+// One pass over the canvas tiles (Apply's tile loop, .cpp:478-492): the tiles this shard owns, their bounding box,
+// the hash cells they fall in (for the need rectangles) and the table entries: slot address | fresh bit | culled cells.
+// The reference's own per-frame O(tiles) cost is d->data() at .cpp:477.
+//
+// Cull (round 4): a cell of a tile in which this keyframe cannot win the max-weight select at ANY level is left out of the launch -- a
+// tile whose cells are all out keeps table entry 0, exactly as if another shard owned it, and the level-0 blocks' own need test / the
+// need rectangles shrink the grid to what the remaining cells depend on.  Nothing changes in what is stored: `if (srcW >= dstW)`
+// (.cpp:521, :542) is false at every pixel of such a cell.  Sound because both sides are bounded from the geometry alone, with margins
+// (cell_out):
+//   new weights   W_i(q) is a convex combination (pyrDown) of level-0 radial weights inside the cell dilated by the pyramid's
+//                 support radius 2^(L+1) px, so W_i <= wmax = the largest radial weight the frame can have there;
+//   stored ones   every earlier keyframe f whose canvas held the tile left S_i >= W_i^f >= wmin_f (its smallest weight on the same
+//                 dilated cell, 0 unless that lies wholly inside f's footprint) -- also when f itself was culled there, for
+//                 then S_i > W_i^f.  Tile::wlb[cell] = max over f of wmin_f.
+// Bit-exactness is checked, not assumed: every parity test runs with the cull on; PF_CULL=0 turns it off.
+// The unit of the cull is a CELL of a tile (64 x 64 pixels, 16 per tile; experiments library, PF_CULL_SUB=2: a quadrant), dilated by the
+// pyramid's support radius 2^(L+1) - 2 pixels rounded up to the lattice step (62 -> 64 for five bands, 254 -> 256 for seven).  A tile whose
+// cells are all out is left out of the launch; otherwise the cells that are out travel as flag bits of its table entry and the kernels do
+// not look at their pixels (kernels.hip, cell_culled), which may have been computed from input nobody produced.
+bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
+{
+    const int tx = w.tx, ty = w.ty, L = w.L;
+    w.sharded = opt_.shard_count > 1;
+    const bool sharded = w.sharded;
+    w.cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(w.M0, w.Minv) && cull_frame_ok(w.Minv, w.crows, w.ccols);
+    const bool cull = w.cull;
     const int S = cull_sub_, span = 4 / S;                       // cells per tile edge; lattice steps per cell
-    if (cull) raise.reserve((size_t)tx * ty * S * S);
-    std::vector<Tile*> culled;
-    if (cull) cull_lattice(Minv, crows, ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
-    bool culled_any = false;
-    struct Cell { int cx, cy, x0, y0, x1, y1; };              // hash cell; box of what is rendered in it, level-0 pixels
-    Cell cells[64]; int ncells = 0; bool cells_overflow = false;
+    if (cull) w.raise.reserve((size_t)tx * ty * S * S);
+    if (cull) cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
     const int B = opt_.shard_block;
-    // cells of the need rectangles: a shard's hash cells; for the cull alone squares of 8 x 8 tiles as well (PF_CULL_CELL, A/B)
-    static const int bc_env = std::getenv("PF_CULL_CELL") ? std::atoi(std::getenv("PF_CULL_CELL")) : 0;
+    // cells of the need rectangles: a shard's hash cells; for the cull alone squares of 8 x 8 tiles as well (experiments library: PF_CULL_CELL)
+    static const int bc_env = exp_env_int("PF_CULL_CELL", 0);
     const int Bc = sharded ? B : (bc_env > 0 ? bc_env : 8);      // measured (profiles/r04_ab.md): 8 beats 3 / 4 (fewer, tighter-merging rectangles; less host work)
     table_tmp_.resize((size_t)tx * ty);
-    std::vector<Tile*> touched;
-    touched.reserve((size_t)tx * ty);
-    int bx0 = tx, bx1 = 0, by0 = ty, by1 = 0, owned = 0, owned_all = 0;
+    w.touched.reserve((size_t)tx * ty);
+    w.bx0 = tx; w.bx1 = 0; w.by0 = ty; w.by1 = 0;
     // the same box in level-0 pixels, around the cells that are rendered (== the tiles' box when nothing is culled); the squares of the rectangles likewise
-    int pbx0 = 1 << 30, pbx1 = 0, pby0 = 1 << 30, pby1 = 0;
+    w.pbx0 = 1 << 30; w.pbx1 = 0; w.pby0 = 1 << 30; w.pby1 = 0;
     auto add_rect = [&](int sx, int sy, int x0, int y0, int x1, int y1) {
-        pbx0 = std::min(pbx0, x0); pbx1 = std::max(pbx1, x1); pby0 = std::min(pby0, y0); pby1 = std::max(pby1, y1);
-        if (!(sharded || cull) || cells_overflow) return;
+        w.pbx0 = std::min(w.pbx0, x0); w.pbx1 = std::max(w.pbx1, x1); w.pby0 = std::min(w.pby0, y0); w.pby1 = std::max(w.pby1, y1);
+        if (!(sharded || cull) || w.cells_overflow) return;
         const int cx = floordiv(sx, Bc), cy = floordiv(sy, Bc);
-        int k = ncells - 1;
-        while (k >= 0 && !(cells[k].cx == cx && cells[k].cy == cy)) k--;
+        int k = w.ncells - 1;
+        while (k >= 0 && !(w.cells[k].cx == cx && w.cells[k].cy == cy)) k--;
         if (k < 0) {
-            if (ncells == 64) cells_overflow = true;
-            else cells[ncells++] = Cell{ cx, cy, x0, y0, x1, y1 };
+            if (w.ncells == 64) w.cells_overflow = true;
+            else w.cells[w.ncells++] = FrameWork::Cell{ cx, cy, x0, y0, x1, y1 };
         } else {
-            Cell& c = cells[k];
+            FrameWork::Cell& c = w.cells[k];
             c.x0 = std::min(c.x0, x0); c.y0 = std::min(c.y0, y0); c.x1 = std::max(c.x1, x1); c.y1 = std::max(c.y1, y1);
         }
     };
     for (int y = 0; y < ty; y++) {
-        const int sy = yminInt + y + off_y_;
+        const int sy = w.yminInt + y + off_y_;
         for (int x = 0; x < tx; x++) {
-            const int sx = xminInt + x + off_x_;
+            const int sx = w.xminInt + x + off_x_;
             uint64_t ent = 0;
             if (!sharded || tile_owner(opt_.shard_count, B, sx, sy) == opt_.shard_rank) {
                 Tile* t = store_.get_or_create(sx, sy);
                 if (!t) return false;
-                owned_all++;
+                w.owned_all++;
                 unsigned out = 0;                                  // 64 x 64 cells in which this keyframe cannot win (bit 4 * row + column)
                 if (cull) {
                     // the whole tile first, against the smallest of its cells' bounds: out there is out in every cell (the tile's dilated
@@ -801,21 +857,21 @@ bool FusionMap::render_frame(const QueuedFrame& f)
                         float wmin;
                         if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, t->wlb[q], !t->fresh && !tile_out, &wmin) || tile_out)
                             out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
-                        if (wmin > t->wlb[q]) raise.push_back(Raise{ t, q, wmin });
+                        if (wmin > t->wlb[q]) w.raise.push_back(FrameWork::Raise{ t, q, wmin });
                     }
                     if (out == 0xffffu) {
                         // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
                         // (.cpp:553), and draw() re-blends it with whatever its neighbours have become
-                        culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; culled.push_back(t);
+                        w.culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++; w.culled.push_back(t);
                         continue;
                     }
-                    if (out) { culled_any = true; n_culled_cells_ += __builtin_popcount(out); }
+                    if (out) { w.culled_any = true; n_culled_cells_ += __builtin_popcount(out); }
                 }
                 if ((uint64_t)(uintptr_t)t->base >> 48) { set_error("tile slot address above 2^48: the table entry has no room for the cell flags"); return false; }
                 ent = (uint64_t)(uintptr_t)t->base | (t->fresh ? 1u : 0u) | ((uint64_t)out << 48);
-                touched.push_back(t);
-                owned++;
-                bx0 = std::min(bx0, x); bx1 = std::max(bx1, x + 1); by0 = std::min(by0, y); by1 = std::max(by1, y + 1);
+                w.touched.push_back(t);
+                w.owned++;
+                w.bx0 = std::min(w.bx0, x); w.bx1 = std::max(w.bx1, x + 1); w.by0 = std::min(w.by0, y); w.by1 = std::max(w.by1, y + 1);
                 if (!out) add_rect(sx, sy, x * kElePixels, y * kElePixels, (x + 1) * kElePixels, (y + 1) * kElePixels);
                 else
                     for (int r = 0; r < 4; r++) {                  // the rendered cells, row by row as runs
@@ -828,430 +884,481 @@ bool FusionMap::render_frame(const QueuedFrame& f)
             table_tmp_[(size_t)y * tx + x] = ent;
         }
     }
-    if (bx0 >= bx1) {                           // nothing of this frame lands on this shard, or it cannot win anywhere it lands
-        for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
-        for (Tile* t : culled) t->changed = true;
-        if (owned_all) n_rendered_++;
-        if (f.seq >= 0) { if (render_log_.size() >= 65536) render_log_.erase(render_log_.begin(), render_log_.begin() + 32768); render_log_.push_back(f.seq); }
-        return true;
-    }
-    px_owned_ += (double)owned * kElePixels * kElePixels;     // what this rank renders beyond its share: owned tile pixels vs the level-0 window (bench --shard strong)
-    n_with_pixels_++;
+    return true;
+}
 
-    // per-level windows: Gaussian level i must be valid on need[i] so that the
-    // Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
-    Win need[kMaxLevels];
-    auto clampw = [](int lo, int hi, int n, int& o0, int& o1) { o0 = std::max(lo, 0); o1 = std::min(hi, n); };
-    // a box of level-0 pixels (multiples of 64) at level i: floor / ceil (at the top levels a cell is less than a pixel)
-    auto lo = [](int p, int i) { return p >> i; };
-    auto hi = [](int p, int i) { return (p + (1 << i) - 1) >> i; };
+// per-level windows: Gaussian level i must be valid on need[i] so that the
+// Laplacian of the owned tiles is exact (pyrDown reads [2p-2, 2q+1), pyrUp +-1)
+void FusionMap::level_windows(FrameWork& w)
+{
+    const int L = w.L;
     for (int i = L; i >= 0; i--) {
-        const int rows = crows >> i, cols = ccols >> i;
-        int x0 = lo(pbx0, i), x1 = hi(pbx1, i), y0 = lo(pby0, i), y1 = hi(pby1, i);
+        const int rows = w.crows >> i, cols = w.ccols >> i;
+        int x0 = lv_lo(w.pbx0, i), x1 = lv_hi(w.pbx1, i), y0 = lv_lo(w.pby0, i), y1 = lv_hi(w.pby1, i);
         if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
         if (i < L) {
-            x0 = std::min(x0, 2 * need[i + 1].x0 - 2); x1 = std::max(x1, 2 * need[i + 1].x1 + 1);
-            y0 = std::min(y0, 2 * need[i + 1].y0 - 2); y1 = std::max(y1, 2 * need[i + 1].y1 + 1);
+            x0 = std::min(x0, 2 * w.need[i + 1].x0 - 2); x1 = std::max(x1, 2 * w.need[i + 1].x1 + 1);
+            y0 = std::min(y0, 2 * w.need[i + 1].y0 - 2); y1 = std::max(y1, 2 * w.need[i + 1].y1 + 1);
         }
-        clampw(x0, x1, cols, need[i].x0, need[i].x1);
-        clampw(y0, y1, rows, need[i].y0, need[i].y1);
+        clampw(x0, x1, cols, w.need[i].x0, w.need[i].x1);
+        clampw(y0, y1, rows, w.need[i].y0, w.need[i].y1);
     }
     // level 0 is produced by the warp in 64x4 blocks
-    need[0].x0 = (need[0].x0 / 64) * 64; need[0].x1 = std::min(ccols, ((need[0].x1 + 63) / 64) * 64);
-    need[0].y0 = (need[0].y0 / 4) * 4;   need[0].y1 = std::min(crows, ((need[0].y1 + 3) / 4) * 4);
+    w.need[0].x0 = (w.need[0].x0 / 64) * 64; w.need[0].x1 = std::min(w.ccols, ((w.need[0].x1 + 63) / 64) * 64);
+    w.need[0].y0 = (w.need[0].y0 / 4) * 4;   w.need[0].y1 = std::min(w.crows, ((w.need[0].y1 + 3) / 4) * 4);
+}
 
-    // workspace
+// grow-only workspace: per-frame Gaussian levels (GW_i of the fused forms, G_i / W_i of the per-op form) and the tile-table ring
+bool FusionMap::reserve_frame_workspace(FrameWork& w)
+{
+    const int L = w.L, tx = w.tx, ty = w.ty;
     const size_t es = lay_.f32 ? 4 : 2;
     const bool fused = opt_.fused != 0 && L >= 1;
     const size_t pxb = level_px_bytes(lay_.f32 != 0);
     bool grow = false;
     for (int i = 0; i <= L; i++) {
-        const size_t n = (size_t)(crows >> i) * (ccols >> i);
+        const size_t n = (size_t)(w.crows >> i) * (w.ccols >> i);
         if (single_band_) continue;
         if (fused) { if (i >= 1 && i < L && (gw_[i].cap < n * pxb || gw2_[i].cap < n * pxb)) grow = true; }
         else if (g_[i].cap < n * 3 * es || wgt_[i].cap < n * 4) grow = true;
     }
     if (table_cap_ < (size_t)tx * ty) grow = true;
-    if (grow) {
-        HIP_OK(sync_all());
-        for (int i = 0; i <= L; i++) {
-            const size_t n = (size_t)(crows >> i) * (ccols >> i);
-            if (single_band_) continue;
-            if (fused) { if (i >= 1 && i < L && (!gw_[i].reserve(n * pxb) || !gw2_[i].reserve(n * pxb))) return false; }
-            else if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
-        }
-        if (table_cap_ < (size_t)tx * ty) {
-            table_cap_ = (size_t)tx * ty * 2;
-            for (int i = 0; i < kTableRing; i++) {
-                if (table_host_[i]) (void)hipHostFree(table_host_[i]);
-                HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, hipHostMallocDefault));
-                if (!table_dev_[i].reserve(table_cap_ * 8)) return false;
-                table_pending_[i] = false;
-            }
+    if (!grow) return true;
+    HIP_OK(sync_all());
+    for (int i = 0; i <= L; i++) {
+        const size_t n = (size_t)(w.crows >> i) * (w.ccols >> i);
+        if (single_band_) continue;
+        if (fused) { if (i >= 1 && i < L && (!gw_[i].reserve(n * pxb) || !gw2_[i].reserve(n * pxb))) return false; }
+        else if (!g_[i].reserve(n * 3 * es) || !wgt_[i].reserve(n * 4)) return false;
+    }
+    if (table_cap_ < (size_t)tx * ty) {
+        table_cap_ = (size_t)tx * ty * 2;
+        for (int i = 0; i < kTableRing; i++) {
+            if (table_host_[i]) (void)hipHostFree(table_host_[i]);
+            HIP_OK(hipHostMalloc((void**)&table_host_[i], table_cap_ * 8, hipHostMallocDefault));
+            if (!table_dev_[i].reserve(table_cap_ * 8)) return false;
+            table_pending_[i] = false;
         }
     }
+    return true;
+}
 
-    // the frame's tile table -> ring slot in device memory
-    const int ring = (int)(frame_seq_++ % kTableRing);
+// the frame's tile table -> ring slot in device memory: inside the kernel arguments of the pipelined launch (which stores it there
+// itself), or staged in pinned memory and copied in the stream
+bool FusionMap::place_table(FrameWork& w)
+{
+    const int tx = w.tx, ty = w.ty;
+    w.ring = (int)(frame_seq_++ % kTableRing);
+    const int ring = w.ring;
     if (table_pending_[ring]) { HIP_OK(hipEventSynchronize(table_ev_[ring])); table_pending_[ring] = false; }
-    const bool table_args = table_in_args_ && opt_.fused == 1 && !single_band_ && L >= 2 && (size_t)tx * ty <= (size_t)kArgTable;
-    if (!table_args) {
+    w.table_args = table_in_args_ && opt_.fused == 1 && !single_band_ && w.L >= 2 && (size_t)tx * ty <= (size_t)kArgTable;
+    if (!w.table_args) {
         // staged in pinned memory and copied in the stream; the staging slot is reused once that copy has run
         if (!wait_for(table_release_[ring])) return false;
         std::memcpy(table_host_[ring], table_tmp_.data(), (size_t)tx * ty * 8);
         HIP_OK(hipMemcpyAsync(table_dev_[ring].p, table_host_[ring], (size_t)tx * ty * 8, hipMemcpyHostToDevice, stream_));
     }
-    const uint64_t* dtab = (const uint64_t*)table_dev_[ring].p;
+    w.dtab = (const uint64_t*)table_dev_[ring].p;
+    return true;
+}
 
-    // warp (.cpp:443-452)
-    WarpArgs a{};
-    if (!invert3x3(M0, a.M)) std::memset(a.M, 0, sizeof(a.M));
+// warp (.cpp:443-452): destination -> source map, window, radial weight constants
+void FusionMap::warp_args(const QueuedFrame& f, FrameWork& w)
+{
+    WarpArgs& a = w.a;
+    a = WarpArgs{};
+    if (!invert3x3(w.M0, a.M)) std::memset(a.M, 0, sizeof(a.M));
     a.srows = f.rows; a.scols = f.cols; a.sstep = f.step;
-    a.crows = crows; a.ccols = ccols;
-    a.y_off = need[0].y0; a.x_off = need[0].x0; a.wrows = need[0].y1 - need[0].y0; a.wcols = need[0].x1 - need[0].x0;
+    a.crows = w.crows; a.ccols = w.ccols;
+    a.y_off = w.need[0].y0; a.x_off = w.need[0].x0; a.wrows = w.need[0].y1 - w.need[0].y0; a.wcols = w.need[0].x1 - w.need[0].x0;
     a.xc = (float)(f.cols / 2); a.yc = (float)(f.rows / 2);
     a.dis_max = std::sqrt(a.xc * a.xc + a.yc * a.yc);
     a.weight_type = opt_.weight_type;
     a.src_cn = f.cn == 4 ? 4 : 3;
-    if (single_band_) {
-        // Map2DCPU::renderFrame (Map2DCPU.cpp:236-334): per-pixel work only, so a shard needs no halo
-        if (w8_rows_ != f.rows || w8_cols_ != f.cols) {
-            HIP_OK(sync_all());
-            if (!w8_.reserve((size_t)f.rows * f.cols)) return false;
-            launch_weight8(stream_, (uint8_t*)w8_.p, f.rows, f.cols, opt_.weight_type);
-            w8_rows_ = f.rows; w8_cols_ = f.cols;
-        }
-        a.y_off = by0 * kElePixels; a.x_off = bx0 * kElePixels;
-        a.wrows = (by1 - by0) * kElePixels; a.wcols = (bx1 - bx0) * kElePixels;
-        prof_begin(K_SINGLE, (double)a.src_cn * f.rows * f.cols + (double)a.wrows * a.wcols * 8);
-        launch_single(stream_, src, (const uint8_t*)w8_.p, a, dtab, tx);
-        prof_end();
-    } else if (fused) {
-        // weightImage (MultiBandMap2DCPU.cpp:396-425): built once per frame size, gathered by the warp
-        if (wmap_rows_ != f.rows || wmap_cols_ != f.cols) {
-            HIP_OK(sync_all());
-            if (!wmap_.reserve((size_t)f.rows * f.cols * 4)) return false;
-            launch_weight32(stream_, (float*)wmap_.p, f.rows, f.cols, opt_.weight_type);
-            wmap_rows_ = f.rows; wmap_cols_ = f.cols;
-        }
-        a.wmap = (const float*)wmap_.p;
-        // compute regions: level i's launch must cover the owned tiles and produce GW_{i+1}
-        // wherever the level i+1 launch stages its halo (its region -4 / +3)
-        Win C[kMaxLevels];
-        for (int i = L - 1; i >= 0; i--) {
-            const int rows = crows >> i, cols = ccols >> i;
-            // the origin stays even (a block's quads and its part of level i+1 start on even pixels): a box of 64-pixel cells is odd at level 6
-            int x0 = lo(pbx0, i) & ~1, x1 = hi(pbx1, i), y0 = lo(pby0, i) & ~1, y1 = hi(pby1, i);
-            if (i < L - 1) {
-                x0 = std::min(x0, 2 * (C[i + 1].x0 - 4)); x1 = std::max(x1, 2 * (C[i + 1].x1 + 3));
-                y0 = std::min(y0, 2 * (C[i + 1].y0 - 4)); y1 = std::max(y1, 2 * (C[i + 1].y1 + 3));
-            }
-            clampw(x0, x1, cols, C[i].x0, C[i].x1);
-            clampw(y0, y1, rows, C[i].y0, C[i].y1);
-        }
-        const double E = 3 * es + 4;
-        // A shard's tiles are scattered hash cells, and the compute regions above are their bounding box: per level, one
-        // rectangle of 64x32 blocks per cell says where something owned depends on a block (the same recursion as `need`,
-        // applied per cell); blocks outside every rectangle exit at once.  (Unsharded: every block is needed, no rectangles.)
-        BlockRect rects[kMaxLevels][kMaxRects];
-        int nrect[kMaxLevels] = {};
-        int need_n_tmp[kMaxLevels] = {};
-        // Upper levels: one bit per block of the level's grid -- does a rendered cell lie within the pyramid's reach of it (the rule the
-        // level-0 blocks apply to themselves in the kernel: (3 * 2^(L-i) - 2) level-i pixels)?  From row bitmaps of the rendered cells
-        // (canvases up to 32 tiles wide); the jobs carry them in their launches' kernel arguments, the rectangles stay as the fallback.
-        if ((sharded || culled_any) && !cells_overflow && 4 * tx <= 128 && L >= 2) {
-            const int BHr = level_block_rows(lay_.f32 != 0);
-            typedef unsigned __int128 u128;
-            cell_rows_.assign((size_t)4 * ty, 0);
-            for (int y = 0; y < ty; y++)
-                for (int x = 0; x < tx; x++) {
-                    const uint64_t e = table_tmp_[(size_t)y * tx + x];
-                    if (!e) continue;
-                    const unsigned in = ~(unsigned)(e >> 48) & 0xffffu;
-                    for (int r = 0; r < 4; r++) cell_rows_[(size_t)4 * y + r] |= (u128)((in >> (4 * r)) & 15u) << (4 * x);
-                }
-            for (int i = 1; i < L; i++) {
-                const int reach = ((3 << (L - i)) - 2) << i, nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
-                need_n_tmp[i] = 0;
-                if (nbx <= 0 || nby <= 0 || (nbx * nby + 31) / 32 > kNeedWords) continue;
-                uint32_t* bits = need_tmp_[i];
-                std::memset(bits, 0, sizeof(uint32_t) * (size_t)((nbx * nby + 31) / 32));
-                for (int gy = 0; gy < nby; gy++) {
-                    const int y0 = std::max(((C[i].y0 + gy * BHr) << i) - reach, 0) >> 6, y1 = std::min((((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach) >> 6, 4 * ty - 1);
-                    u128 rowsum = 0;
-                    for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
-                    if (!rowsum) continue;
-                    for (int gx = 0; gx < nbx; gx++) {
-                        const int x0 = std::max(((C[i].x0 + gx * 64) << i) - reach, 0) >> 6, x1 = std::min((((C[i].x0 + gx * 64 + 64) << i) - 1 + reach) >> 6, 4 * tx - 1);
-                        if (x0 > x1) continue;
-                        const u128 m = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
-                        if (rowsum & m) { const int b = gy * nbx + gx; bits[(size_t)b >> 5] |= 1u << (b & 31); }
-                    }
-                }
-                need_n_tmp[i] = nbx * nby;
-            }
-        }
-        double owned_tiles = owned_all, blocks_run0 = 0;          // algorithmic bytes: every canvas tile of this rank, culled or not
-        if ((sharded || culled_any) && opt_.fused == 1 && !cells_overflow) {
-            const int BHr = level_block_rows(lay_.f32 != 0);
-            struct R { int x0, y0, x1, y1; };
-            std::vector<R> lv[kMaxLevels];
-            for (int c = 0; c < ncells; c++) {
-                // N[i]: where Gaussian level i is needed for this cell's tiles (pixel-exact: pyrDown reads [2p-2, 2p+2],
-                // pyrUp +-1).  The level-i block at b runs iff it holds owned pixels or its part of level i+1 lies in
-                // N[i+1]; what else it computes from unproduced input is never read.
-                const Cell& ce = cells[c];
-                Win N[kMaxLevels];
-                for (int i = L; i >= 0; i--) {
-                    const int rows = crows >> i, cols = ccols >> i;
-                    int x0 = lo(ce.x0, i), x1 = hi(ce.x1, i), y0 = lo(ce.y0, i), y1 = hi(ce.y1, i);
-                    if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
-                    if (i < L) {
-                        x0 = std::min(x0, 2 * N[i + 1].x0 - 2); x1 = std::max(x1, 2 * N[i + 1].x1 + 1);
-                        y0 = std::min(y0, 2 * N[i + 1].y0 - 2); y1 = std::max(y1, 2 * N[i + 1].y1 + 1);
-                    }
-                    clampw(x0, x1, cols, N[i].x0, N[i].x1);
-                    clampw(y0, y1, rows, N[i].y0, N[i].y1);
-                }
-                for (int i = 0; i < L; i++) {
-                    int x0 = std::min(lo(ce.x0, i), 2 * N[i + 1].x0), x1 = std::max(hi(ce.x1, i), 2 * N[i + 1].x1);
-                    int y0 = std::min(lo(ce.y0, i), 2 * N[i + 1].y0), y1 = std::max(hi(ce.y1, i), 2 * N[i + 1].y1);
-                    x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
-                    if (x0 >= x1 || y0 >= y1) continue;
-                    lv[i].push_back(R{ (x0 - C[i].x0) / 64, (y0 - C[i].y0) / BHr, (x1 - C[i].x0 + 63) / 64, (y1 - C[i].y0 + BHr - 1) / BHr });
-                }
-            }
-            for (int i = 0; i < L; i++) {
-                // at most kMaxRects (level 0) / kMaxRectsUpper travel with a job: merge the pair whose common bounding box adds the fewest blocks
-                // (extra blocks only cost time: they hold no owned pixel and write no tile)
-                std::vector<R>& v = lv[i];
-                auto area = [](const R& r) { return (long)(r.x1 - r.x0) * (r.y1 - r.y0); };
-                const int cap = i == 0 ? kMaxRects : kMaxRectsUpper;       // what a job of this level can carry (kernels.hpp)
-                while ((int)v.size() > cap) {
-                    size_t ba = 0, bb = 1; long best = -1;
-                    for (size_t p = 0; p < v.size(); p++)
-                        for (size_t q = p + 1; q < v.size(); q++) {
-                            const R u{ std::min(v[p].x0, v[q].x0), std::min(v[p].y0, v[q].y0), std::max(v[p].x1, v[q].x1), std::max(v[p].y1, v[q].y1) };
-                            const long add = area(u) - area(v[p]) - area(v[q]);
-                            if (best < 0 || add < best) { best = add; ba = p; bb = q; }
-                        }
-                    v[ba] = R{ std::min(v[ba].x0, v[bb].x0), std::min(v[ba].y0, v[bb].y0), std::max(v[ba].x1, v[bb].x1), std::max(v[ba].y1, v[bb].y1) };
-                    v.erase(v.begin() + bb);
-                }
-                nrect[i] = (int)v.size();
-                for (int k = 0; k < nrect[i]; k++) rects[i][k] = BlockRect{ (short)v[k].x0, (short)v[k].y0, (short)v[k].x1, (short)v[k].y1 };
-                if (v.empty()) { nrect[i] = 1; rects[i][0] = BlockRect{ 0, 0, 0, 0 }; }      // nothing needed at this level: an empty rectangle
-            }
-            if (need_n_tmp[1] > 0 && level0_need_reach(lay_, table_args ? tx * ty : 0, nrect[0]) > 0) {
-                // the level-0 blocks pick themselves in the kernel (within 94 px of a rendered cell): counted through the level-1 bitmap, whose
-                // blocks are 2 x 2 of them under nearly the same rule (92 px)
-                int n1 = 0;
-                for (int w = 0; w < (need_n_tmp[1] + 31) / 32; w++) n1 += __builtin_popcount(need_tmp_[1][w]);
-                blocks_run0 = std::min(4.0 * n1, (double)((C[0].x1 - C[0].x0 + 63) / 64) * ((C[0].y1 - C[0].y0 + BHr - 1) / BHr));
-            } else {   // level-0 blocks that run (render_stats, bench --shard strong)
-                const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
-                block_bits_.assign((size_t)std::max(nbx, 0) * std::max(nby, 0), 0);
-                for (int k = 0; k < nrect[0]; k++)
-                    for (int gy = rects[0][k].y0; gy < rects[0][k].y1; gy++)
-                        if (rects[0][k].x1 > rects[0][k].x0) std::memset(block_bits_.data() + (size_t)gy * nbx + rects[0][k].x0, 1, (size_t)(rects[0][k].x1 - rects[0][k].x0));
-                for (uint8_t v : block_bits_) blocks_run0 += v;
-            }
-            px_level0_ += blocks_run0 * 64 * BHr;
-            static const bool exact_stat = std::getenv("PF_CULL_EXACT_STAT") != nullptr;
-            if (exact_stat) {       // diagnostics: level-0 blocks within the pyramid's reach (94 px for five bands) of a cell that is rendered
-                const int R0 = 94, nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
-                long cnt = 0;
-                for (int gy = 0; gy < nby; gy++)
-                    for (int gx = 0; gx < nbx; gx++) {
-                        const int x0 = C[0].x0 + gx * 64 - R0, x1 = C[0].x0 + gx * 64 + 63 + R0, y0 = C[0].y0 + gy * BHr - R0, y1 = C[0].y0 + gy * BHr + BHr - 1 + R0;
-                        bool need = false;
-                        for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
-                            for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
-                                const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
-                                need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
-                            }
-                        cnt += need;
-                    }
-                px_level0_exact_ += (double)cnt * 64 * BHr;
-                // the same question for the upper levels: blocks inside the need rectangles against blocks within the pyramid's reach of a
-                // rendered cell (printed every 100 keyframes)
-                static double up_rect[kMaxLevels] = {}, up_exact[kMaxLevels] = {}; static long up_n = 0;
-                for (int i = 1; i < L; i++) {
-                    const int reach = ((3 << (L - i)) - 2) << i, nbxi = (C[i].x1 - C[i].x0 + 63) / 64, nbyi = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
-                    for (int gy = 0; gy < nbyi; gy++)
-                        for (int gx = 0; gx < nbxi; gx++) {
-                            bool inr = false;
-                            for (int k = 0; k < nrect[i]; k++) inr = inr || (gx >= rects[i][k].x0 && gx < rects[i][k].x1 && gy >= rects[i][k].y0 && gy < rects[i][k].y1);
-                            up_rect[i] += inr;
-                            const int x0 = ((C[i].x0 + gx * 64) << i) - reach, x1 = ((C[i].x0 + gx * 64 + 64) << i) - 1 + reach;
-                            const int y0 = ((C[i].y0 + gy * BHr) << i) - reach, y1 = ((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach;
-                            bool need = false;
-                            for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
-                                for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
-                                    const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
-                                    need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
-                                }
-                            up_exact[i] += need;
-                        }
-                }
-                if (++up_n % 100 == 0)
-                    for (int i = 1; i < L; i++) std::fprintf(stderr, "upper level %d: blocks in rectangles %.1f, within reach of a rendered cell %.1f per keyframe\n", i, up_rect[i] / up_n, up_exact[i] / up_n);
-            }
-        } else
-            px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
-        if (opt_.fused == 1) {
-            // Share of each level's canvas pixels (this rank's tiles) that the blocks which RUN cover: 1 unless the cull or a shard leaves
-            // blocks out.  Level 0 with the blocks' own need test (k_levels, need_r0): the same rule evaluated here from the rendered cells'
-            // row bitmaps -- exactly, for the launches that are bracketed by events (10 us of host time), through the level-1 bitmap otherwise.
-            double run_share[kMaxLevels];
-            int exact_r0 = 0;
-            for (int i = 0; i < kMaxLevels; i++) run_share[i] = 1.0;
-            if ((sharded || culled_any) && !cells_overflow) {
-                const int BHr = level_block_rows(lay_.f32 != 0);
-                for (int i = 0; i < L; i++) {
-                    const int nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
-                    if (nbx <= 0 || nby <= 0) continue;
-                    double run = 0;
-                    const int r0 = i == 0 && need_n_tmp[1] > 0 ? level0_need_reach(lay_, table_args ? tx * ty : 0, nrect[0]) : 0;
-                    if (i == 0 && r0 > 0 && prof_would(K_LEVEL0) && cell_rows_.size() == (size_t)4 * ty) {
-                        exact_r0 = r0;                              // counted exactly AFTER the launch is out (below): ~50 us of host time that must not delay it
-                        run = blocks_run0;
-                    } else if (i == 0) run = blocks_run0;
-                    else if (need_n_tmp[i] > 0) { for (int w = 0; w < (need_n_tmp[i] + 31) / 32; w++) run += __builtin_popcount(need_tmp_[i][w]); }
-                    else {
-                        block_bits_.assign((size_t)nbx * nby, 0);
-                        for (int k = 0; k < nrect[i]; k++)
-                            for (int gy = std::max<int>(rects[i][k].y0, 0); gy < std::min<int>(rects[i][k].y1, nby); gy++)
-                                for (int gx = std::max<int>(rects[i][k].x0, 0); gx < std::min<int>(rects[i][k].x1, nbx); gx++) block_bits_[(size_t)gy * nbx + gx] = 1;
-                        for (uint8_t v : block_bits_) run += v;
-                        if (!nrect[i]) run = (double)nbx * nby;
-                    }
-                    const double ts = kElePixels >> i;
-                    run_share[i] = std::min(1.0, run * 64.0 * BHr / std::max(1.0, owned_tiles * ts * ts));
-                }
-            }
-            // one launch per keyframe: this frame's level 0 plus the pending upper levels of the frames before it
-            PipeFrame cur;
-            cur.valid = true; cur.ring = ring; cur.tx = tx; cur.crows = crows; cur.ccols = ccols;
-            for (int i = 0; i < L; i++) {
-                cur.C[i] = C[i]; cur.nrect[i] = nrect[i];
-                for (int k = 0; k < nrect[i]; k++) cur.rect[i][k] = rects[i][k];
-                const double ts = kElePixels >> i, n = owned_tiles * ts * ts;
-                // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
-                const double tile_bytes = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0), frame_bytes_read = i == 0 ? (double)a.src_cn * f.rows * f.cols : 0;
-                cur.bytes[i] = tile_bytes + frame_bytes_read;                         // every canvas tile of this rank, culled or not
-                cur.bytes_run[i] = tile_bytes * run_share[i] + frame_bytes_read;      // the part of the canvas whose blocks run
-            }
-            if (table_args) { cur.table_args = table_tmp_.data(); cur.table_n = tx * ty; }
-            for (int i = 1; i < L; i++) { cur.need_n[i] = need_n_tmp[i]; if (need_n_tmp[i] > 0) std::memcpy(cur.need_bits[i], need_tmp_[i], sizeof(uint32_t) * (size_t)((need_n_tmp[i] + 31) / 32)); }
-            if (!launch_pipeline(&cur, &a, src)) return false;
-            if (exact_r0 > 0 && prof_on_ && !prof_pending_.empty()) {
-                // this launch is bracketed by events: replace the level-0 job's estimated run share in its record by the exact one (the blocks' own
-                // need rule, k_levels need_r0, from the rendered cells' row bitmaps) -- now that the launch is on its way
-                typedef unsigned __int128 u128;
-                const int BHr = level_block_rows(lay_.f32 != 0), r0 = exact_r0;
-                const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
-                // (the column masks once per launch, one AND per block: ~8 us for cfg-A's 7072 blocks)
-                static thread_local std::vector<u128> colmask;
-                colmask.assign((size_t)std::max(nbx, 0), 0);
-                for (int gx = 0; gx < nbx; gx++) {
-                    const int x0 = std::max(C[0].x0 + gx * 64 - r0, 0) >> 6, x1 = std::min(C[0].x0 + gx * 64 + 63 + r0, ccols - 1) >> 6;
-                    if (x0 <= x1) colmask[(size_t)gx] = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
-                }
-                long run = 0;
-                for (int gy = 0; gy < nby; gy++) {
-                    const int y0 = std::max(C[0].y0 + gy * BHr - r0, 0) >> 6, y1 = std::min(C[0].y0 + gy * BHr + BHr - 1 + r0, crows - 1) >> 6;
-                    u128 rowsum = 0;
-                    for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
-                    if (!rowsum) continue;
-                    const uint64_t lo = (uint64_t)rowsum, hi = (uint64_t)(rowsum >> 64);
-                    for (int gx = 0; gx < nbx; gx++) run += ((lo & (uint64_t)colmask[(size_t)gx]) | (hi & (uint64_t)(colmask[(size_t)gx] >> 64))) != 0;
-                }
-                const double n0 = owned_tiles * kElePixels * kElePixels, tile_bytes0 = n0 * (4 + E) + (L == 1 ? n0 / 4 * (4 + E) : 0);
-                const double share = std::min(1.0, run * 64.0 * BHr / std::max(1.0, n0));
-                prof_pending_.back().bytes_run += tile_bytes0 * (share - run_share[0]);
-            }
-        } else {
-        // fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
-        // Level i of frame f runs after level i-1 of frame f (GW_i, event) and, by stream order, after level i of
-        // frame f-1 (tiles are updated in feed order).  GW buffers are double-buffered by frame parity; a writer
-        // waits for the reader two frames back.
-        const unsigned long long fidx = frame_seq_ - 1;
-        const int slot = (int)(fidx % kLvlRing);
-        DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
-        for (int i = 0; i < L; i++) {
-            if (!lvl_stream_[i]) {
-                // HIP multiplexes streams onto a few hardware queues (4 by default), and streams that share one
-                // serialize: keep the count small.  Level 0 has its own stream, the upper levels -- a dependent
-                // chain within a frame anyway -- share kUpperStreams (PF_LEVEL_STREAMS, diagnostics).
-                static const int n_upper = std::getenv("PF_LEVEL_STREAMS") ? std::atoi(std::getenv("PF_LEVEL_STREAMS")) : kUpperStreams;
-                if (i == 0) lvl_stream_[0] = stream_;
-                else if (std::getenv("PF_SINGLE_STREAM") || n_upper <= 0) lvl_stream_[i] = stream_;      // diagnostics: serial kernel times
-                else if (i > n_upper) lvl_stream_[i] = lvl_stream_[1 + (i - 1) % n_upper];
-                else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
-            }
-            for (int k = 0; k < kLvlRing; k++)
-                if (!lvl_ev_[i][k]) HIP_OK(hipEventCreateWithFlags(&lvl_ev_[i][k], hipEventDisableTiming));
-        }
-        for (int i = 0; i < L; i++) {
-            hipStream_t st = lvl_stream_[i];
-            const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
-            const bool top = (i + 1 == L);
-            if (i > 0) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i - 1][slot], 0));
-            if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kLvlRing)], 0));
-            // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
-            double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
-            if (i == 0) bytes += (double)a.src_cn * f.rows * f.cols;
-            prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
-            launch_level(st, lay_, i, crows >> i, ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, tx, top, !top,
-                         i == 0 ? &a : nullptr, src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, dtab, opt_.fused);   // 2: 4-stage k_level, 3: k_level3
-            prof_end();
-            HIP_OK(hipEventRecord(lvl_ev_[i][slot], st));
-        }
-        // the tile table of this ring slot is read until the last level has run
-        HIP_OK(hipEventRecord(table_ev_[ring], lvl_stream_[L - 1]));
-        table_pending_[ring] = true;
-        }
-    } else {
-    const double win0 = (double)a.wrows * a.wcols;
-    prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
-    launch_warp(stream_, lay_.f32, src, a, g_[0].p, (float*)wgt_[0].p);
-    prof_end();
+}
 
-    // Gaussian pyramids (.cpp:469 first loop, .cpp:471-474)
-    for (int i = 0; i < L; i++) {
-        const Win& d = need[i + 1];
-        const double nd = (double)(d.x1 - d.x0) * (d.y1 - d.y0);
-        prof_begin(K_PYRDOWN_IMG, nd * 4 * 3 * es + nd * 3 * es);
-        launch_pyrdown(stream_, lay_.f32 ? 1 : 0, g_[i].p, crows >> i, ccols >> i, g_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
-        prof_end();
-        prof_begin(K_PYRDOWN_W, nd * 4 * 4 + nd * 4);
-        launch_pyrdown(stream_, 2, wgt_[i].p, crows >> i, ccols >> i, wgt_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
-        prof_end();
+// Map2DCPU::renderFrame (Map2DCPU.cpp:236-334): per-pixel work only, so a shard needs no halo
+bool FusionMap::launch_single_band(const QueuedFrame& f, FrameWork& w)
+{
+    WarpArgs& a = w.a;
+    if (w8_rows_ != f.rows || w8_cols_ != f.cols) {
+        HIP_OK(sync_all());
+        if (!w8_.reserve((size_t)f.rows * f.cols)) return false;
+        launch_weight8(stream_, (uint8_t*)w8_.p, f.rows, f.cols, opt_.weight_type);
+        w8_rows_ = f.rows; w8_cols_ = f.cols;
     }
-    // Laplacian + select into tiles (.cpp:469 second loop, .cpp:476-555)
-    for (int i = 0; i <= L; i++) {
-        const double ts = kElePixels >> i, n = (double)(bx1 - bx0) * (by1 - by0) * ts * ts;
-        prof_begin(K_LAP_SELECT, n * (3 * es + 4 + 4) + (i < L ? n / 4 * 3 * es : 0));
-        launch_lap_select(stream_, lay_, i, g_[i].p, i < L ? g_[i + 1].p : nullptr, (const float*)wgt_[i].p,
-                          crows >> i, ccols >> i, dtab, tx, by0, by1, bx0, bx1);
-        prof_end();
-    }
-    }
-    HIP_OK(hipGetLastError());
-    if (!table_pending_[ring] && !(fused && opt_.fused == 1)) {
-        // this frame's kernels were the last readers of its tile table (fused = 1 retires it in launch_pipeline)
-        if (!submitted()) return false;
-        table_release_[ring] = work_no_;
-    }
-    if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
-    for (Tile* t : touched) { t->fresh = false; t->changed = true; }
-    for (Tile* t : culled) t->changed = true;
-    for (auto& r : raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
-    n_rendered_++;
-    if (f.seq >= 0) { if (render_log_.size() >= 65536) render_log_.erase(render_log_.begin(), render_log_.begin() + 32768); render_log_.push_back(f.seq); }
+    a.y_off = w.by0 * kElePixels; a.x_off = w.bx0 * kElePixels;
+    a.wrows = (w.by1 - w.by0) * kElePixels; a.wcols = (w.bx1 - w.bx0) * kElePixels;
+    prof_begin(K_SINGLE, (double)a.src_cn * f.rows * f.cols + (double)a.wrows * a.wcols * 8);
+    launch_single(stream_, w.src, (const uint8_t*)w8_.p, a, w.dtab, w.tx);
+    prof_end();
     return true;
 }
+
+// Fused forms: where the level kernels run.
+//   C[i]         compute region of level i: its launch must cover the owned tiles and produce GW_{i+1} wherever the level i+1
+//                launch stages its halo (its region -4 / +3)
+//   need bitmaps upper levels: one bit per block of the level's grid -- does a rendered cell lie within the pyramid's reach of it (the
+//                rule the level-0 blocks apply to themselves in the kernel: (3 * 2^(L-i) - 2) level-i pixels)?  From row bitmaps of the
+//                rendered cells (canvases up to 32 tiles wide); the jobs carry them in their launches' kernel arguments
+//   rectangles   a shard's tiles are scattered hash cells, and the compute regions are their bounding box: per level, one rectangle of
+//                64x32 blocks per cell says where something owned depends on a block (the same recursion as `need`, applied per
+//                cell); blocks outside every rectangle exit at once.  The fallback of the bitmaps.  (Unsharded, no cull: every block runs.)
+void FusionMap::plan_fused_levels(FrameWork& w)
+{
+    const int L = w.L, tx = w.tx, ty = w.ty, crows = w.crows, ccols = w.ccols;
+    Win* C = w.C;
+    for (int i = L - 1; i >= 0; i--) {
+        const int rows = crows >> i, cols = ccols >> i;
+        // the origin stays even (a block's quads and its part of level i+1 start on even pixels): a box of 64-pixel cells is odd at level 6
+        int x0 = lv_lo(w.pbx0, i) & ~1, x1 = lv_hi(w.pbx1, i), y0 = lv_lo(w.pby0, i) & ~1, y1 = lv_hi(w.pby1, i);
+        if (i < L - 1) {
+            x0 = std::min(x0, 2 * (C[i + 1].x0 - 4)); x1 = std::max(x1, 2 * (C[i + 1].x1 + 3));
+            y0 = std::min(y0, 2 * (C[i + 1].y0 - 4)); y1 = std::max(y1, 2 * (C[i + 1].y1 + 3));
+        }
+        clampw(x0, x1, cols, C[i].x0, C[i].x1);
+        clampw(y0, y1, rows, C[i].y0, C[i].y1);
+    }
+    const bool partial = (w.sharded || w.culled_any) && !w.cells_overflow;
+    const int BHr = level_block_rows(lay_.f32 != 0);
+    if (partial && 4 * tx <= 128 && L >= 2) {
+        typedef unsigned __int128 u128;
+        cell_rows_.assign((size_t)4 * ty, 0);
+        for (int y = 0; y < ty; y++)
+            for (int x = 0; x < tx; x++) {
+                const uint64_t e = table_tmp_[(size_t)y * tx + x];
+                if (!e) continue;
+                const unsigned in = ~(unsigned)(e >> 48) & 0xffffu;
+                for (int r = 0; r < 4; r++) cell_rows_[(size_t)4 * y + r] |= (u128)((in >> (4 * r)) & 15u) << (4 * x);
+            }
+        for (int i = 1; i < L; i++) {
+            const int reach = ((3 << (L - i)) - 2) << i, nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+            w.need_n[i] = 0;
+            if (nbx <= 0 || nby <= 0 || (nbx * nby + 31) / 32 > kNeedWords) continue;
+            uint32_t* bits = need_tmp_[i];
+            std::memset(bits, 0, sizeof(uint32_t) * (size_t)((nbx * nby + 31) / 32));
+            for (int gy = 0; gy < nby; gy++) {
+                const int y0 = std::max(((C[i].y0 + gy * BHr) << i) - reach, 0) >> 6, y1 = std::min((((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach) >> 6, 4 * ty - 1);
+                u128 rowsum = 0;
+                for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
+                if (!rowsum) continue;
+                for (int gx = 0; gx < nbx; gx++) {
+                    const int x0 = std::max(((C[i].x0 + gx * 64) << i) - reach, 0) >> 6, x1 = std::min((((C[i].x0 + gx * 64 + 64) << i) - 1 + reach) >> 6, 4 * tx - 1);
+                    if (x0 > x1) continue;
+                    const u128 m = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
+                    if (rowsum & m) { const int b = gy * nbx + gx; bits[(size_t)b >> 5] |= 1u << (b & 31); }
+                }
+            }
+            w.need_n[i] = nbx * nby;
+        }
+    }
+    if (!(partial && opt_.fused == 1)) {
+        px_level0_ += (double)(C[0].x1 - C[0].x0) * (C[0].y1 - C[0].y0);
+        return;
+    }
+    struct R { int x0, y0, x1, y1; };
+    std::vector<R> lv[kMaxLevels];
+    for (int c = 0; c < w.ncells; c++) {
+        // N[i]: where Gaussian level i is needed for this cell's tiles (pixel-exact: pyrDown reads [2p-2, 2p+2],
+        // pyrUp +-1).  The level-i block at b runs iff it holds owned pixels or its part of level i+1 lies in
+        // N[i+1]; what else it computes from unproduced input is never read.
+        const FrameWork::Cell& ce = w.cells[c];
+        Win N[kMaxLevels];
+        for (int i = L; i >= 0; i--) {
+            const int rows = crows >> i, cols = ccols >> i;
+            int x0 = lv_lo(ce.x0, i), x1 = lv_hi(ce.x1, i), y0 = lv_lo(ce.y0, i), y1 = lv_hi(ce.y1, i);
+            if (i > 0) { x0 -= 1; x1 += 1; y0 -= 1; y1 += 1; }
+            if (i < L) {
+                x0 = std::min(x0, 2 * N[i + 1].x0 - 2); x1 = std::max(x1, 2 * N[i + 1].x1 + 1);
+                y0 = std::min(y0, 2 * N[i + 1].y0 - 2); y1 = std::max(y1, 2 * N[i + 1].y1 + 1);
+            }
+            clampw(x0, x1, cols, N[i].x0, N[i].x1);
+            clampw(y0, y1, rows, N[i].y0, N[i].y1);
+        }
+        for (int i = 0; i < L; i++) {
+            int x0 = std::min(lv_lo(ce.x0, i), 2 * N[i + 1].x0), x1 = std::max(lv_hi(ce.x1, i), 2 * N[i + 1].x1);
+            int y0 = std::min(lv_lo(ce.y0, i), 2 * N[i + 1].y0), y1 = std::max(lv_hi(ce.y1, i), 2 * N[i + 1].y1);
+            x0 = std::max(x0, C[i].x0); y0 = std::max(y0, C[i].y0); x1 = std::min(x1, C[i].x1); y1 = std::min(y1, C[i].y1);
+            if (x0 >= x1 || y0 >= y1) continue;
+            lv[i].push_back(R{ (x0 - C[i].x0) / 64, (y0 - C[i].y0) / BHr, (x1 - C[i].x0 + 63) / 64, (y1 - C[i].y0 + BHr - 1) / BHr });
+        }
+    }
+    for (int i = 0; i < L; i++) {
+        // at most kMaxRects (level 0) / kMaxRectsUpper travel with a job: merge the pair whose common bounding box adds the fewest blocks
+        // (extra blocks only cost time: they hold no owned pixel and write no tile)
+        std::vector<R>& v = lv[i];
+        auto area = [](const R& r) { return (long)(r.x1 - r.x0) * (r.y1 - r.y0); };
+        const int cap = i == 0 ? kMaxRects : kMaxRectsUpper;       // what a job of this level can carry (kernels.hpp)
+        while ((int)v.size() > cap) {
+            size_t ba = 0, bb = 1; long best = -1;
+            for (size_t p = 0; p < v.size(); p++)
+                for (size_t q = p + 1; q < v.size(); q++) {
+                    const R u{ std::min(v[p].x0, v[q].x0), std::min(v[p].y0, v[q].y0), std::max(v[p].x1, v[q].x1), std::max(v[p].y1, v[q].y1) };
+                    const long add = area(u) - area(v[p]) - area(v[q]);
+                    if (best < 0 || add < best) { best = add; ba = p; bb = q; }
+                }
+            v[ba] = R{ std::min(v[ba].x0, v[bb].x0), std::min(v[ba].y0, v[bb].y0), std::max(v[ba].x1, v[bb].x1), std::max(v[ba].y1, v[bb].y1) };
+            v.erase(v.begin() + bb);
+        }
+        w.nrect[i] = (int)v.size();
+        for (int k = 0; k < w.nrect[i]; k++) w.rects[i][k] = BlockRect{ (short)v[k].x0, (short)v[k].y0, (short)v[k].x1, (short)v[k].y1 };
+        if (v.empty()) { w.nrect[i] = 1; w.rects[i][0] = BlockRect{ 0, 0, 0, 0 }; }      // nothing needed at this level: an empty rectangle
+    }
+    // level-0 blocks that run (render_stats, bench --shard strong; the numerator of roofline.frac)
+    if (w.need_n[1] > 0 && level0_need_reach(lay_, w.table_args ? tx * ty : 0, w.nrect[0]) > 0) {
+        // the level-0 blocks pick themselves in the kernel (within 94 px of a rendered cell): counted through the level-1 bitmap, whose
+        // blocks are 2 x 2 of them under nearly the same rule (92 px)
+        int n1 = 0;
+        for (int k = 0; k < (w.need_n[1] + 31) / 32; k++) n1 += __builtin_popcount(need_tmp_[1][k]);
+        w.blocks_run0 = std::min(4.0 * n1, (double)((C[0].x1 - C[0].x0 + 63) / 64) * ((C[0].y1 - C[0].y0 + BHr - 1) / BHr));
+    } else {
+        const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+        block_bits_.assign((size_t)std::max(nbx, 0) * std::max(nby, 0), 0);
+        for (int k = 0; k < w.nrect[0]; k++)
+            for (int gy = w.rects[0][k].y0; gy < w.rects[0][k].y1; gy++)
+                if (w.rects[0][k].x1 > w.rects[0][k].x0) std::memset(block_bits_.data() + (size_t)gy * nbx + w.rects[0][k].x0, 1, (size_t)(w.rects[0][k].x1 - w.rects[0][k].x0));
+        for (uint8_t v : block_bits_) w.blocks_run0 += v;
+    }
+    px_level0_ += w.blocks_run0 * 64 * BHr;
+#if PF_EXPERIMENTS
+    static const bool exact_stat = exp_env("PF_CULL_EXACT_STAT") != nullptr;
+    if (exact_stat) cull_exact_stat(w);
+#endif
+}
+
+// Accounting of a pipelined launch: share of each level's canvas pixels (this rank's tiles) that the blocks which RUN cover: 1 unless the
+// cull or a shard leaves blocks out.  Level 0 with the blocks' own need test (k_levels, need_r0): through the level-1 bitmap here, and --
+// for the launches that are bracketed by events -- exactly, after the launch is out (exact_level0_share).
+void FusionMap::run_shares(const FrameWork& w, double run_share[kMaxLevels], int* exact_r0)
+{
+    const int L = w.L;
+    const Win* C = w.C;
+    *exact_r0 = 0;
+    for (int i = 0; i < kMaxLevels; i++) run_share[i] = 1.0;
+    if (!((w.sharded || w.culled_any) && !w.cells_overflow)) return;
+    const int BHr = level_block_rows(lay_.f32 != 0);
+    for (int i = 0; i < L; i++) {
+        const int nbx = (C[i].x1 - C[i].x0 + 63) / 64, nby = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+        if (nbx <= 0 || nby <= 0) continue;
+        double run = 0;
+        const int r0 = i == 0 && w.need_n[1] > 0 ? level0_need_reach(lay_, w.table_args ? w.tx * w.ty : 0, w.nrect[0]) : 0;
+        if (i == 0 && r0 > 0 && prof_would(K_LEVEL0) && cell_rows_.size() == (size_t)4 * w.ty) {
+            *exact_r0 = r0;                             // counted exactly AFTER the launch is out: ~50 us of host time that must not delay it
+            run = w.blocks_run0;
+        } else if (i == 0) run = w.blocks_run0;
+        else if (w.need_n[i] > 0) { for (int k = 0; k < (w.need_n[i] + 31) / 32; k++) run += __builtin_popcount(need_tmp_[i][k]); }
+        else {
+            block_bits_.assign((size_t)nbx * nby, 0);
+            for (int k = 0; k < w.nrect[i]; k++)
+                for (int gy = std::max<int>(w.rects[i][k].y0, 0); gy < std::min<int>(w.rects[i][k].y1, nby); gy++)
+                    for (int gx = std::max<int>(w.rects[i][k].x0, 0); gx < std::min<int>(w.rects[i][k].x1, nbx); gx++) block_bits_[(size_t)gy * nbx + gx] = 1;
+            for (uint8_t v : block_bits_) run += v;
+            if (!w.nrect[i]) run = (double)nbx * nby;
+        }
+        const double ts = kElePixels >> i;
+        run_share[i] = std::min(1.0, run * 64.0 * BHr / std::max(1.0, (double)w.owned_all * ts * ts));
+    }
+}
+
+// the blocks' own need rule (k_levels need_r0) evaluated from the rendered cells' row bitmaps: the share of the level-0 canvas pixels
+// that the blocks which run cover (the column masks once per launch, one AND per block: ~8 us for cfg-A's 7072 blocks)
+double FusionMap::exact_level0_share(const FrameWork& w, int r0)
+{
+    typedef unsigned __int128 u128;
+    const Win* C = w.C;
+    const int BHr = level_block_rows(lay_.f32 != 0);
+    const int nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+    static thread_local std::vector<u128> colmask;
+    colmask.assign((size_t)std::max(nbx, 0), 0);
+    for (int gx = 0; gx < nbx; gx++) {
+        const int x0 = std::max(C[0].x0 + gx * 64 - r0, 0) >> 6, x1 = std::min(C[0].x0 + gx * 64 + 63 + r0, w.ccols - 1) >> 6;
+        if (x0 <= x1) colmask[(size_t)gx] = (x1 - x0 >= 127 ? ~(u128)0 : (((u128)1 << (x1 - x0 + 1)) - 1)) << x0;
+    }
+    long run = 0;
+    for (int gy = 0; gy < nby; gy++) {
+        const int y0 = std::max(C[0].y0 + gy * BHr - r0, 0) >> 6, y1 = std::min(C[0].y0 + gy * BHr + BHr - 1 + r0, w.crows - 1) >> 6;
+        u128 rowsum = 0;
+        for (int r = y0; r <= y1; r++) rowsum |= cell_rows_[(size_t)r];
+        if (!rowsum) continue;
+        const uint64_t lo = (uint64_t)rowsum, hi = (uint64_t)(rowsum >> 64);
+        for (int gx = 0; gx < nbx; gx++) run += ((lo & (uint64_t)colmask[(size_t)gx]) | (hi & (uint64_t)(colmask[(size_t)gx] >> 64))) != 0;
+    }
+    const double n0 = (double)w.owned_all * kElePixels * kElePixels;
+    return std::min(1.0, run * 64.0 * BHr / std::max(1.0, n0));
+}
+
+// fused = 1: one launch per keyframe -- this frame's level 0 plus the pending upper levels of the frames before it
+bool FusionMap::launch_fused_pipeline(const QueuedFrame& f, FrameWork& w)
+{
+    const int L = w.L;
+    const size_t es = lay_.f32 ? 4 : 2;
+    const double E = 3 * es + 4, owned_tiles = w.owned_all;       // algorithmic bytes: every canvas tile of this rank, culled or not
+    double run_share[kMaxLevels];
+    int exact_r0 = 0;
+    run_shares(w, run_share, &exact_r0);
+    PipeFrame cur;
+    cur.valid = true; cur.ring = w.ring; cur.tx = w.tx; cur.crows = w.crows; cur.ccols = w.ccols;
+    for (int i = 0; i < L; i++) {
+        cur.C[i] = w.C[i]; cur.nrect[i] = w.nrect[i];
+        for (int k = 0; k < w.nrect[i]; k++) cur.rect[i][k] = w.rects[i][k];
+        const double ts = kElePixels >> i, n = owned_tiles * ts * ts;
+        // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
+        const double tile_bytes = n * (4 + E) + (i + 1 == L ? n / 4 * (4 + E) : 0), frame_bytes_read = i == 0 ? (double)w.a.src_cn * f.rows * f.cols : 0;
+        cur.bytes[i] = tile_bytes + frame_bytes_read;                         // every canvas tile of this rank, culled or not
+        cur.bytes_run[i] = tile_bytes * run_share[i] + frame_bytes_read;      // the part of the canvas whose blocks run
+    }
+    if (w.table_args) { cur.table_args = table_tmp_.data(); cur.table_n = w.tx * w.ty; }
+    for (int i = 1; i < L; i++) { cur.need_n[i] = w.need_n[i]; if (w.need_n[i] > 0) std::memcpy(cur.need_bits[i], need_tmp_[i], sizeof(uint32_t) * (size_t)((w.need_n[i] + 31) / 32)); }
+    if (!launch_pipeline(&cur, &w.a, w.src)) return false;
+    if (exact_r0 > 0 && prof_on_ && !prof_pending_.empty()) {
+        // this launch is bracketed by events: replace the level-0 job's estimated run share in its record by the exact one -- now that
+        // the launch is on its way
+        const double n0 = owned_tiles * kElePixels * kElePixels, tile_bytes0 = n0 * (4 + E) + (L == 1 ? n0 / 4 * (4 + E) : 0);
+        prof_pending_.back().bytes_run += tile_bytes0 * (exact_level0_share(w, exact_r0) - run_share[0]);
+    }
+    return true;
+}
+
+// fused = 2 / 3: one launch per level, level 0 on stream_ and the upper levels on kUpperStreams more.
+// Level i of frame f runs after level i-1 of frame f (GW_i, event) and, by stream order, after level i of
+// frame f-1 (tiles are updated in feed order).  GW buffers are double-buffered by frame parity; a writer
+// waits for the reader two frames back.
+bool FusionMap::launch_level_streams(const QueuedFrame& f, FrameWork& w)
+{
+    const int L = w.L;
+    const size_t es = lay_.f32 ? 4 : 2;
+    const double E = 3 * es + 4;
+    const Win* C = w.C;
+    const unsigned long long fidx = frame_seq_ - 1;
+    const int slot = (int)(fidx % kLvlRing);
+    DevBuf* gw = (fidx & 1) ? gw2_ : gw_;
+    for (int i = 0; i < L; i++) {
+        if (!lvl_stream_[i]) {
+            // HIP multiplexes streams onto a few hardware queues (4 by default), and streams that share one
+            // serialize: keep the count small.  Level 0 has its own stream, the upper levels -- a dependent
+            // chain within a frame anyway -- share kUpperStreams (experiments library: PF_LEVEL_STREAMS, PF_SINGLE_STREAM).
+            static const int n_upper = exp_env_int("PF_LEVEL_STREAMS", kUpperStreams);
+            if (i == 0) lvl_stream_[0] = stream_;
+            else if (exp_env("PF_SINGLE_STREAM") || n_upper <= 0) lvl_stream_[i] = stream_;      // diagnostics: serial kernel times
+            else if (i > n_upper) lvl_stream_[i] = lvl_stream_[1 + (i - 1) % n_upper];
+            else HIP_OK(hipStreamCreateWithFlags(&lvl_stream_[i], hipStreamNonBlocking));
+        }
+        for (int k = 0; k < kLvlRing; k++)
+            if (!lvl_ev_[i][k]) HIP_OK(hipEventCreateWithFlags(&lvl_ev_[i][k], hipEventDisableTiming));
+    }
+    for (int i = 0; i < L; i++) {
+        hipStream_t st = lvl_stream_[i];
+        const double ts = kElePixels >> i, n = (double)(w.bx1 - w.bx0) * (w.by1 - w.by0) * ts * ts;
+        const bool top = (i + 1 == L);
+        if (i > 0) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i - 1][slot], 0));
+        if (!top && fidx >= 2) HIP_OK(hipStreamWaitEvent(st, lvl_ev_[i + 1][(int)((fidx - 2) % kLvlRing)], 0));
+        // algorithmic bytes: frame read once + per tile-level pixel 4 (stored weight) + E (payload)
+        double bytes = n * (4 + E) + (top ? n / 4 * (4 + E) : 0);
+        if (i == 0) bytes += (double)w.a.src_cn * f.rows * f.cols;
+        prof_begin(i == 0 ? K_LEVEL0 : K_LEVEL, bytes, st);
+        launch_level(st, lay_, i, w.crows >> i, w.ccols >> i, C[i].x0, C[i].y0, C[i].x1, C[i].y1, w.tx, top, !top,
+                     i == 0 ? &w.a : nullptr, w.src, i == 0 ? nullptr : gw[i].p, top ? nullptr : gw[i + 1].p, w.dtab, opt_.fused);   // 2: 4-stage k_level, 3: k_level3
+        prof_end();
+        HIP_OK(hipEventRecord(lvl_ev_[i][slot], st));
+    }
+    // the tile table of this ring slot is read until the last level has run
+    HIP_OK(hipEventRecord(table_ev_[w.ring], lvl_stream_[L - 1]));
+    table_pending_[w.ring] = true;
+    return true;
+}
+
+// fused = 0: one kernel per reference op -- warp (.cpp:443-452), the Gaussian pyramids (.cpp:469 first loop, .cpp:471-474),
+// Laplacian + select into tiles (.cpp:469 second loop, .cpp:476-555)
+bool FusionMap::launch_per_op(const QueuedFrame& f, FrameWork& w)
+{
+    const int L = w.L;
+    const size_t es = lay_.f32 ? 4 : 2;
+    const double win0 = (double)w.a.wrows * w.a.wcols;
+    prof_begin(K_WARP, 3.0 * f.rows * f.cols + win0 * (3 * es + 4));
+    launch_warp(stream_, lay_.f32, w.src, w.a, g_[0].p, (float*)wgt_[0].p);
+    prof_end();
+    for (int i = 0; i < L; i++) {
+        const Win& d = w.need[i + 1];
+        const double nd = (double)(d.x1 - d.x0) * (d.y1 - d.y0);
+        prof_begin(K_PYRDOWN_IMG, nd * 4 * 3 * es + nd * 3 * es);
+        launch_pyrdown(stream_, lay_.f32 ? 1 : 0, g_[i].p, w.crows >> i, w.ccols >> i, g_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
+        prof_end();
+        prof_begin(K_PYRDOWN_W, nd * 4 * 4 + nd * 4);
+        launch_pyrdown(stream_, 2, wgt_[i].p, w.crows >> i, w.ccols >> i, wgt_[i + 1].p, d.y0, d.y1, d.x0, d.x1);
+        prof_end();
+    }
+    for (int i = 0; i <= L; i++) {
+        const double ts = kElePixels >> i, n = (double)(w.bx1 - w.bx0) * (w.by1 - w.by0) * ts * ts;
+        prof_begin(K_LAP_SELECT, n * (3 * es + 4 + 4) + (i < L ? n / 4 * 3 * es : 0));
+        launch_lap_select(stream_, lay_, i, g_[i].p, i < L ? g_[i + 1].p : nullptr, (const float*)wgt_[i].p,
+                          w.crows >> i, w.ccols >> i, w.dtab, w.tx, w.by0, w.by1, w.bx0, w.bx1);
+        prof_end();
+    }
+    return true;
+}
+
+// the keyframe is in: its table slot and frame slot retire with the launches, the tiles it touched carry pixels and want a redraw
+// (Ischanged, .cpp:553), the cull's weight bounds take this keyframe's
+bool FusionMap::retire_frame(const QueuedFrame& f, FrameWork& w, bool fused)
+{
+    if (!table_pending_[w.ring] && !(fused && opt_.fused == 1)) {
+        // this frame's kernels were the last readers of its tile table (fused = 1 retires it in launch_pipeline)
+        if (!submitted()) return false;
+        table_release_[w.ring] = work_no_;
+    }
+    if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
+    for (Tile* t : w.touched) { t->fresh = false; t->changed = true; }
+    for (Tile* t : w.culled) t->changed = true;
+    for (auto& r : w.raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
+    n_rendered_++;
+    log_rendered(f);
+    return true;
+}
+
+#if PF_EXPERIMENTS
+// experiments library, PF_CULL_EXACT_STAT=1: level-0 blocks within the pyramid's reach (94 px for five bands) of a cell that is rendered, and
+// the same question for the upper levels -- blocks inside the need rectangles against blocks within reach of a rendered cell (printed
+// every 100 keyframes).  The accumulators are members: two maps on two threads do not share them.
+void FusionMap::cull_exact_stat(const FrameWork& w)
+{
+    const int L = w.L, tx = w.tx, crows = w.crows, ccols = w.ccols, BHr = level_block_rows(lay_.f32 != 0);
+    const Win* C = w.C;
+    const int R0 = 94, nbx = (C[0].x1 - C[0].x0 + 63) / 64, nby = (C[0].y1 - C[0].y0 + BHr - 1) / BHr;
+    long cnt = 0;
+    for (int gy = 0; gy < nby; gy++)
+        for (int gx = 0; gx < nbx; gx++) {
+            const int x0 = C[0].x0 + gx * 64 - R0, x1 = C[0].x0 + gx * 64 + 63 + R0, y0 = C[0].y0 + gy * BHr - R0, y1 = C[0].y0 + gy * BHr + BHr - 1 + R0;
+            bool need = false;
+            for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
+                for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
+                    const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
+                    need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
+                }
+            cnt += need;
+        }
+    px_level0_exact_ += (double)cnt * 64 * BHr;
+    for (int i = 1; i < L; i++) {
+        const int reach = ((3 << (L - i)) - 2) << i, nbxi = (C[i].x1 - C[i].x0 + 63) / 64, nbyi = (C[i].y1 - C[i].y0 + BHr - 1) / BHr;
+        for (int gy = 0; gy < nbyi; gy++)
+            for (int gx = 0; gx < nbxi; gx++) {
+                bool inr = false;
+                for (int k = 0; k < w.nrect[i]; k++) inr = inr || (gx >= w.rects[i][k].x0 && gx < w.rects[i][k].x1 && gy >= w.rects[i][k].y0 && gy < w.rects[i][k].y1);
+                up_rect_[i] += inr;
+                const int x0 = ((C[i].x0 + gx * 64) << i) - reach, x1 = ((C[i].x0 + gx * 64 + 64) << i) - 1 + reach;
+                const int y0 = ((C[i].y0 + gy * BHr) << i) - reach, y1 = ((C[i].y0 + gy * BHr + BHr) << i) - 1 + reach;
+                bool need = false;
+                for (int qy = std::max(y0, 0) >> 6; qy <= (std::min(y1, crows - 1) >> 6) && !need; qy++)
+                    for (int qx = std::max(x0, 0) >> 6; qx <= (std::min(x1, ccols - 1) >> 6) && !need; qx++) {
+                        const uint64_t e = table_tmp_[(size_t)(qy >> 2) * tx + (qx >> 2)];
+                        need = e != 0 && !((e >> (48 + (qy & 3) * 4 + (qx & 3))) & 1);
+                    }
+                up_exact_[i] += need;
+            }
+    }
+    if (++up_n_ % 100 == 0)
+        for (int i = 1; i < L; i++) std::fprintf(stderr, "upper level %d: blocks in rectangles %.1f, within reach of a rendered cell %.1f per keyframe\n", i, up_rect_[i] / up_n_, up_exact_[i] / up_n_);
+}
+#endif
 
 int FusionMap::render_log(long long* out, int cap)
 {
@@ -1431,7 +1538,7 @@ bool FusionMap::launch_pipeline(const PipeFrame* cur, const WarpArgs* wa, const 
     };
     // level 0 first: the short upper-level blocks come last and fill the tail of the grid
     if (cur) add(*cur, 0);
-    static const bool no_upper = std::getenv("PF_NO_UPPER") != nullptr;       // diagnostics (timing only, wrong tiles): what the upper-level jobs add to a launch
+    static const bool no_upper = exp_env("PF_NO_UPPER") != nullptr;           // experiments library (timing only, wrong tiles): what the upper-level jobs add to a launch
     for (int s = 1; s < L; s++) if (pipe_[s].valid && !no_upper) add(pipe_[s], s);
     if (n) {
         prof_begin(cur ? K_LEVEL0 : K_LEVEL, bytes, stream_, bytes_run);
@@ -1716,7 +1823,7 @@ bool FusionMap::blend_batch(const std::vector<std::pair<int, int>>& tiles, const
 {
     Section sec(this, T_UPDATE_TEXTURE);
 #if PF_EXPERIMENTS
-    static const bool per_level = std::getenv("PF_BLEND_PER_LEVEL") != nullptr;
+    static const bool per_level = exp_env("PF_BLEND_PER_LEVEL") != nullptr;
     if (per_level) return blend_batch_per_level(tiles, halo9, raw_host, bgr_host);
 #endif
     const int nl = band_num_ + 1;
@@ -1982,7 +2089,7 @@ bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int
     const size_t out_bytes = (size_t)*rows * *cols * 3;
     if (!blend_out_bgr_.reserve(out_bytes)) return false;
 #if PF_EXPERIMENTS
-    static const bool per_level = std::getenv("PF_BLEND_PER_LEVEL") != nullptr;
+    static const bool per_level = exp_env("PF_BLEND_PER_LEVEL") != nullptr;
     if (per_level) {                              // rounds 1-5: paste per level, one collapse launch per level, finish
         for (int i = 0; i <= L; i++) {
             const size_t n = (size_t)(*rows >> i) * (*cols >> i);

@@ -4,6 +4,7 @@
 #include "../../include/pifusion.h"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "env.hpp"
 #include <hip/hip_runtime.h>
 #include <condition_variable>
 #include <cstdlib>
@@ -209,11 +210,11 @@ private:
     long long n_culled_cells_ = 0;              // 64 x 64 cells of rendered tiles switched off by it
     // Margins of the cull's bounds (cell_out): source pixels added to / taken from a distance before it becomes a weight (the nearest-pixel
     // rounding of the weight gather, 0.71 px, and the float arithmetic of the kernels), and what is taken from / added to a weight (the
-    // pyramid's own rounding).  PF_CULL_MARGIN_PX / PF_CULL_MARGIN_W override them for the sensitivity runs of tools/cull_soak.py
+    // pyramid's own rounding).  PF_CULL_MARGIN_PX / PF_CULL_MARGIN_W (experiments library) override them for the sensitivity runs of tools/cull_soak.py
     // (profiles/r05_cull_margins.md: mismatches against the oracle per setting -- the safety factor, measured); defaults 2 px, 1e-5.
-    double cull_margin_px_ = std::getenv("PF_CULL_MARGIN_PX") ? std::atof(std::getenv("PF_CULL_MARGIN_PX")) : 2.0;
-    double cull_margin_w_ = std::getenv("PF_CULL_MARGIN_W") ? std::atof(std::getenv("PF_CULL_MARGIN_W")) : 1e-5;
-    int cull_sub_ = (std::getenv("PF_CULL_SUB") && std::atoi(std::getenv("PF_CULL_SUB")) == 2) ? 2 : 4;      // cells per tile edge (A/B: 2 = quadrants)
+    double cull_margin_px_ = exp_env_double("PF_CULL_MARGIN_PX", 2.0);
+    double cull_margin_w_ = exp_env_double("PF_CULL_MARGIN_W", 1e-5);
+    int cull_sub_ = exp_env_int("PF_CULL_SUB", 4) == 2 ? 2 : 4;      // cells per tile edge (experiments library: 2 = quadrants)
     struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
@@ -262,6 +263,51 @@ private:
                        uint32_t need_bits[kMaxLevels][kNeedWords]; int need_n[kMaxLevels] = {};    // LevelLaunch::need_bits of the upper levels (need_n 0: none)
                        const uint64_t* table_args = nullptr; int table_n = 0; };            // level 0 only, valid during render_frame
     PipeFrame pipe_[kMaxLevels];
+    // One keyframe on its way through render_frame (MultiBandMap2DCPU::renderFrame, .cpp:311-558): what each stage leaves for the next.
+    // Kept in the map between keyframes so that its vectors keep their capacity (render_frame runs on one thread at a time).
+    struct FrameWork {
+        // frame_canvas(): footprint, tile range, homography
+        double pts[8]; int xminInt, yminInt, xmaxInt, ymaxInt;
+        int tx, ty, L, crows, ccols; double M0[9], Minv[9];
+        const uint8_t* src;
+        // build_tile_table(): the cull, the owned tiles and their boxes (tiles; level-0 pixels), the hash cells of the need rectangles
+        bool sharded, cull, culled_any, cells_overflow;
+        struct Raise { Tile* t; int q; float w; };                // (cell, wmin of this keyframe): applied once the frame is in
+        std::vector<Raise> raise; std::vector<Tile*> culled, touched;
+        struct Cell { int cx, cy, x0, y0, x1, y1; };              // hash cell; box of what is rendered in it, level-0 pixels
+        Cell cells[64]; int ncells;
+        int bx0, bx1, by0, by1, owned, owned_all;
+        int pbx0, pbx1, pby0, pby1;
+        // level_windows() / plan_fused_levels()
+        Win need[kMaxLevels], C[kMaxLevels];
+        BlockRect rects[kMaxLevels][kMaxRects]; int nrect[kMaxLevels]; int need_n[kMaxLevels];
+        double blocks_run0;
+        // place_table() / warp_args()
+        int ring; bool table_args; const uint64_t* dtab;
+        WarpArgs a;
+        void reset() {
+            raise.clear(); culled.clear(); touched.clear();
+            culled_any = cells_overflow = false; ncells = 0; owned = owned_all = 0; blocks_run0 = 0;
+            for (int i = 0; i < kMaxLevels; i++) { nrect[i] = 0; need_n[i] = 0; }
+            src = nullptr; ring = 0; table_args = false; dtab = nullptr; sharded = cull = false;
+        }
+    };
+    FrameWork fw_;
+    int  frame_canvas(const QueuedFrame& f, FrameWork& w);
+    bool build_tile_table(const QueuedFrame& f, FrameWork& w);
+    void level_windows(FrameWork& w);
+    bool reserve_frame_workspace(FrameWork& w);
+    bool place_table(FrameWork& w);
+    void warp_args(const QueuedFrame& f, FrameWork& w);
+    void plan_fused_levels(FrameWork& w);
+    void run_shares(const FrameWork& w, double run_share[kMaxLevels], int* exact_r0);
+    double exact_level0_share(const FrameWork& w, int r0);
+    bool launch_single_band(const QueuedFrame& f, FrameWork& w);
+    bool launch_fused_pipeline(const QueuedFrame& f, FrameWork& w);
+    bool launch_level_streams(const QueuedFrame& f, FrameWork& w);
+    bool launch_per_op(const QueuedFrame& f, FrameWork& w);
+    bool retire_frame(const QueuedFrame& f, FrameWork& w, bool fused);
+    void log_rendered(const QueuedFrame& f);
     uint32_t need_tmp_[kMaxLevels][kNeedWords];     // render_frame scratch: the upper levels' need bitmaps of the keyframe being fed
     std::vector<unsigned __int128> cell_rows_;      // render_frame scratch: rendered cells of the canvas, one 128-bit row per cell row
     unsigned long long launch_seq_ = 0;             // parity selects the GW buffer set a launch writes
@@ -306,7 +352,11 @@ private:
     std::mutex timer_mu_;
     long long n_rendered_ = 0, n_rejected_ = 0, n_dropped_ = 0, n_with_pixels_ = 0;
     long long feed_seq_ = 0; std::vector<long long> render_log_;
-    double px_level0_exact_ = 0;                    // PF_CULL_EXACT_STAT (diagnostics)
+    double px_level0_exact_ = 0;                    // experiments library, PF_CULL_EXACT_STAT (statistics of the cull, cull_exact_stat())
+#if PF_EXPERIMENTS
+    double up_rect_[kMaxLevels] = {}, up_exact_[kMaxLevels] = {}; long up_n_ = 0;
+    void cull_exact_stat(const FrameWork& w);
+#endif
     double px_level0_ = 0, px_owned_ = 0;           // level-0 pixels computed (with halo) / tile pixels owned, over the frames rendered
 };
 

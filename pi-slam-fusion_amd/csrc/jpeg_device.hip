@@ -11,6 +11,7 @@
 //                  3 B out per pixel (4:2:0) -- 54 MB + 54 MB for a 4000 x 3000 frame.
 #include "jpeg_device.hpp"
 #include "jpeg_huff_par.hpp"
+#include "env.hpp"
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
@@ -479,7 +480,7 @@ bool JpegDevice::prepare(int i, const uint8_t* data, size_t len, int rows, int c
 bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
 {
     Slot& s = slot_[i];
-    static const bool host_huffman = getenv("PF_JPEG_HOST_HUFFMAN") != nullptr;          // A/B and tests: the serial pass on the host for every stream
+    static const bool host_huffman = exp_env("PF_JPEG_HOST_HUFFMAN") != nullptr;         // experiments library (A/B, tests): the serial pass on the host for every stream
     if (!host_huffman && skip_par_ > 0) skip_par_--;            // a recent stream of this consumer did not settle: its neighbours will not either
     else if (!host_huffman) {
         // a stream the parallel pass takes: its scan's bytes (stuffing removed) and the plan go to the GPU, nothing else happens here

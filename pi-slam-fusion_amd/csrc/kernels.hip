@@ -10,10 +10,11 @@
 //   k_pyrdown     :469,:474 cv::pyrDown chain (image and weight)
 //   k_lap_select  :469 + :476-555  pyrUp+subtract of createLaplacePyr fused
 //                           with the per-tile max-weight select
-//   k_blend_* / k_collapse  :77-146 Ele::blend, :836 save's collapse
-//   k_mosaic_gather / k_save_finish  :806-840 save
+//   Ele::blend (:77-146) and save (:806-840): collapse_fused.hip; their per-level form of rounds 1-5 (k_blend_* / k_collapse /
+//   k_mosaic_gather / k_save_finish) is compiled into the experiments library only
 #include "kernels.hpp"
 #include "warp_index.hpp"
+#include "env.hpp"
 #include <climits>
 #include <cmath>
 #include <cstdlib>
@@ -1842,10 +1843,10 @@ static bool radial_weight_exact(const WarpArgs& wa) { return wa.srows < 8192 && 
 #include "strips.inc"
 #endif
 
-// FusedWarp::plain: see there.  PF_FORCE_GENERAL=1 (tests) sends every pixel through the general forms.
+// FusedWarp::plain: see there.  Experiments library, PF_FORCE_GENERAL=1 (tests): every pixel through the general forms.
 static int plain_homography(const WarpArgs& wa)
 {
-    static const bool force_general = getenv("PF_FORCE_GENERAL") != nullptr;
+    static const bool force_general = exp_env("PF_FORCE_GENERAL") != nullptr;      // experiments library
     if (force_general || wa.srows > 32767 || wa.scols > 32767) return 0;
     for (int i = 0; i < 9; i++) if (!(std::fabs(wa.M[i]) < 0x1p400)) return 0;
     return 1;
@@ -1951,7 +1952,7 @@ void launch_level(hipStream_t s, const TileLayout& lay, int level, int rows, int
     // k_level3 (2 barriers, no H tile, 2x2 output quads, 64x32 blocks; 73 VGPRs / 51.6 KB LDS fp32 ->
     // 3 workgroups per CU, 56 VGPRs / 38.1 KB int16 -> 4).  Measured on MI355X (cfg-A) k_level3 is
     // the faster one for both pyramid types; shape 2 (pf_options.fused = 2) or PF_KLEVEL=4 selects k_level.
-    static const int force = getenv("PF_KLEVEL") ? atoi(getenv("PF_KLEVEL")) : 0;
+    static const int force = exp_env_int("PF_KLEVEL", 0);                      // experiments library
     static const int ablate = kExp && getenv("PF_ABLATE") ? atoi(getenv("PF_ABLATE")) : 0;
     const bool use4 = force == 4 || (force != 3 && shape == 2);
     const int BH = use4 ? 16 : 32;
@@ -2183,7 +2184,7 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     // The radial weight is computed in the kernel (radial_weight; two gathers per warped pixel instead of three: fp32 +1.8 %, int16 +-0
     // against the weight plane gather, profiles/r03_ab.md) unless the frame is too large for its exactness argument -- those frames, and
     // PF_WEIGHT_PLANE=1 (tests), gather the reference's weightImage plane as fused = 0/2/3 do.
-    static const bool wplane_env = getenv("PF_WEIGHT_PLANE") != nullptr;
+    static const bool wplane_env = exp_env("PF_WEIGHT_PLANE") != nullptr;      // experiments library
     const bool wplane = wplane_env || (wa && !radial_weight_exact(*wa));
     unsigned long long* st = nullptr;
     // Stage A of a level-0 block (level3_block): fp32 -- every row's coordinates, weight and row loads first, every bilinear sum last, the
@@ -2309,6 +2310,7 @@ size_t halo_bytes(const TileLayout& lay, int dx, int dy)
     return n * 3 * (lay.f32 ? 4 : 2);
 }
 
+#if PF_EXPERIMENTS      // the per-level output side of rounds 1-5: A/B partner and second opinion of collapse_fused.hip (PF_BLEND_PER_LEVEL=1)
 // Ele::blend's 3x3 assembly (.cpp:93-117): padded level image of side ts+2b.
 template <bool F32>
 __global__ __launch_bounds__(256) void k_blend_gather(TileLayout lay, int level, int border, const BlendSrc* __restrict__ srcs,
@@ -2460,6 +2462,8 @@ void launch_save_finish(hipStream_t s, const TileLayout& lay, const void* lvl0, 
     if (lay.f32) hipLaunchKernelGGL(k_save_finish<true>, grid, block, 0, s, lay, (const char*)lvl0, table, wx, wy, bg, bgr);
     else         hipLaunchKernelGGL(k_save_finish<false>, grid, block, 0, s, lay, (const char*)lvl0, table, wx, wy, bg, bgr);
 }
+
+#endif  // PF_EXPERIMENTS
 
 // ------------------------------------------------------------- halo pack
 template <bool F32>

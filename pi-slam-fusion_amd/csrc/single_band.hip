@@ -3,6 +3,7 @@
 // (dis*254, floor 2), cv::warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) on 8UC4 through
 // OpenCV's 15-bit fixed-point bilinear taps, select `if (ele.a < dst.a) ele = dst`.
 #include "kernels.hpp"
+#include "env.hpp"
 #include <cmath>
 #include <cstdlib>
 
@@ -242,14 +243,14 @@ __global__ __launch_bounds__(256) void k_single2(const uint8_t* __restrict__ src
 
 void launch_single(hipStream_t s, const uint8_t* src, const uint8_t* w8, const WarpArgs& a, const uint64_t* table, int tiles_x)
 {
-    static const bool old_kernel = getenv("PF_SINGLE_OLD") != nullptr;     // diagnostics: the one-pixel-per-thread form
+    static const bool old_kernel = exp_env("PF_SINGLE_OLD") != nullptr;     // experiments library: the one-pixel-per-thread form
     if (old_kernel) {
         dim3 grid(a.wcols / 64, a.wrows / 4), block(256);
         hipLaunchKernelGGL(k_single, grid, block, 0, s, src, w8, a, table, tiles_x);
         return;
     }
     // plain: see FusedWarp::plain (kernels.hip)
-    int plain = a.srows <= 32767 && a.scols <= 32767 && !getenv("PF_FORCE_GENERAL");
+    int plain = a.srows <= 32767 && a.scols <= 32767 && !exp_env("PF_FORCE_GENERAL");
     for (int i = 0; i < 9; i++) if (!(std::fabs(a.M[i]) < 0x1p400)) plain = 0;
     dim3 grid(a.wcols / 64, a.wrows / 32), block(256);
     hipLaunchKernelGGL(k_single2, grid, block, 0, s, src, w8, a, table, tiles_x, plain);

@@ -130,3 +130,20 @@ def test_product_library_carries_the_product_kernels_only():
         exp = open(exp_path, "rb").read()
         assert b"_ZN2pf8k_stripsI" in exp
         assert len(set(re.findall(rb"_ZN2pf8k_levelsIL[0-9A-Za-z_]+?EEEvNS_10LevelBatchE", exp))) > 10
+
+
+def test_product_library_reads_only_its_documented_environment():
+    """csrc/env.hpp: the product library reads PF_CULL, PF_ROCTX, PF_DIST_VERIFY and PF_COPY_THREADS; A/B switches and timing-only
+    diagnostics (some of which produce wrong tiles) exist in the experiments build alone -- their names are not even among the
+    product's strings (`strings libpifusion.so | grep PF_`)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blob = open(os.path.join(root, "pi-slam-fusion_amd", "libpifusion.so"), "rb").read()
+    names = {m.decode() for m in re.findall(rb"(?<![A-Za-z0-9_])(PF_[A-Z][A-Z0-9_]+)\x00", blob)}
+    assert names == {"PF_CULL", "PF_ROCTX", "PF_DIST_VERIFY", "PF_COPY_THREADS"}, sorted(names)
+    exp = os.path.join(root, "pi-slam-fusion_amd", "libpifusion_exp.so")
+    if os.path.exists(exp):
+        eblob = open(exp, "rb").read()
+        for n in (b"PF_NO_UPPER", b"PF_TABLE_COPY", b"PF_BLEND_PER_LEVEL", b"PF_FORCE_GENERAL", b"PF_CULL_EXACT_STAT"):
+            assert n + b"\x00" in eblob, n

@@ -192,7 +192,9 @@ def test_host_huffman_switch(pf, tmp_path):
             "pf = load_package(); _, s, rgb = vectors()[0]\n"
             "out = torch.zeros(rgb.shape, dtype=torch.uint8, device='cuda'); pf.decode_jpeg_device(s, out.data_ptr(), rgb.shape[0], rgb.shape[1]); torch.cuda.synchronize()\n"
             "assert np.array_equal(out.cpu().numpy()[:, :, ::-1], rgb); print('counts', pf.jpeg_huffman_counts())\n") % (ROOT_DIR, TESTS_DIR)
-    for env_extra, want in (({}, "counts (1, 0,"), ({"PF_JPEG_HOST_HUFFMAN": "1"}, "counts (0, 0,")):
+    exp = os.path.join(ROOT_DIR, "pi-slam-fusion_amd", "libpifusion_exp.so")       # the switch exists in the experiments build only (csrc/env.hpp)
+    assert os.path.exists(exp), "build the experiments library first (__graft_entry__.build())"
+    for env_extra, want in (({}, "counts (1, 0,"), ({"PF_JPEG_HOST_HUFFMAN": "1"}, "counts (1, 0,"), ({"PF_JPEG_HOST_HUFFMAN": "1", "PF_LIB": exp}, "counts (0, 0,")):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
         assert r.returncode == 0 and want in r.stdout.decode(), r.stdout.decode()[-2000:]
 

@@ -320,7 +320,10 @@ def test_general_coordinate_forms(force_float):
         "    assert bad == [], bad[:5]\n"
         "print('general forms ok')\n"
     ) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), force_float)
-    env = dict(os.environ, PF_FORCE_GENERAL="1")
+    # the switch exists in the experiments build of the library only (csrc/env.hpp): the same sources plus the forms not adopted
+    exp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pi-slam-fusion_amd", "libpifusion_exp.so")
+    assert os.path.exists(exp), "build the experiments library first (__graft_entry__.build())"
+    env = dict(os.environ, PF_FORCE_GENERAL="1", PF_LIB=exp)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "general forms ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 

@@ -96,16 +96,27 @@ def test_long_run_three_shards_equal_oracle(pf, orc, force_float):
 
 @pytest.mark.parametrize("force_float", [0, 1])
 def test_table_copy_twin(pf, force_float):
-    """The same long run with PF_TABLE_COPY=1 (tile tables copied to HBM in the stream, the round-1 form): digests
-    must equal the default table path's."""
+    """The same long run with every tile table staged and copied to HBM in the stream (the round-1 form, what canvases of more than 256
+    tiles take in the product): digests must equal the default table path's.  The switch that forces it (PF_TABLE_COPY=1) exists in the
+    experiments build of the library only (csrc/env.hpp), so the twin runs in a child process on that build."""
+    import subprocess, sys
     poses = sortie(N_LONG, seed=3)
     a = map_digest(gpu_run(pf, poses, force_float))
-    os.environ["PF_TABLE_COPY"] = "1"
-    try:
-        b = map_digest(gpu_run(pf, poses, force_float))
-    finally:
-        del os.environ["PF_TABLE_COPY"]
-    assert a == b
+    here = os.path.dirname(os.path.abspath(__file__)); root = os.path.dirname(here)
+    exp = os.path.join(root, "pi-slam-fusion_amd", "libpifusion_exp.so")
+    assert os.path.exists(exp), "build the experiments library first (__graft_entry__.build())"
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from conftest import load_package\nimport test_gpu_steady_state as T\nfrom helpers import map_digest\n"
+            "pf = load_package(); import ctypes as C\n"
+            "d = map_digest(T.gpu_run(pf, T.sortie(T.N_LONG, seed=3), %d))\n"
+            "c = (C.c_longlong * 8)(); pf.lib().pf_debug_form_counts(c)\n"
+            "print('TWIN', json.dumps({'d': d, 'args_launches': c[7]}))\n") % (here, root, force_float)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PF_TABLE_COPY="1", PF_LIB=exp), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import json
+    twin = json.loads([l for l in r.stdout.splitlines() if l.startswith("TWIN ")][-1][5:])
+    assert twin["args_launches"] == 0                                 # no table travelled in the kernel arguments there
+    assert twin["d"] == {k: list(v) for k, v in a.items()}
 
 
 @pytest.mark.parametrize("force_float", [1, 0])

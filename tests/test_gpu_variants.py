@@ -11,8 +11,9 @@ tests in a child process (the switches are read once per process):
   PF_COMPACT=1       a shard's level-0 job on the compact grid (one workgroup per block inside its need rectangles)
   PF_CULL=0          every tile of every canvas rendered (no cull)
   PF_CULL_SUB=2      the cull per quadrant of a tile instead of per 64 x 64 cell
-Forms that were measured and not adopted live in the second build of the library (libpifusion_exp.so, -DPF_EXPERIMENTS=1), which the
-child processes load through PF_LIB; the product library carries the product instantiations only.
+Forms that were measured and not adopted, and every A/B or test switch of a form the product does carry (the weight plane of large frames,
+the copied tile tables of large canvases), live in the second build of the library (libpifusion_exp.so, -DPF_EXPERIMENTS=1), which the
+child processes load through PF_LIB; the product library carries the product instantiations and reads PF_CULL alone of these.
 Reference path: Map2DFusion/MultiBandMap2DCPU.cpp:311-558 (renderFrame)."""
 import os
 import subprocess
@@ -27,7 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # which counter of pf_debug_form_counts must (or must not) move under a switch: the parity run alone would also pass on a silent
 # fall-back to the default form
 EXP_LIB = os.path.join(ROOT, "pi-slam-fusion_amd", "libpifusion_exp.so")
-NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28", "PF_SEED", "PF_COMPACT"}
+# every switch but PF_CULL (a documented runtime option of the product library, csrc/env.hpp) exists in the experiments library only
+NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28", "PF_SEED", "PF_COMPACT", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_CULL_SUB"}
 FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
         "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_A_ILP=0": "c[0] > 0", "PF_SEED": "c[0] > 0", "PF_COMPACT": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
         "PF_CULL=0": "culled == 0 and c[0] > 0", "PF_CULL_SUB=2": "culled > 0 and g.culled_cells() % 4 == 0 and c[0] > 0"}

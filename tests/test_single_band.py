@@ -125,5 +125,7 @@ def test_single_band_other_kernel_forms(env):
         "    assert np.array_equal(g.tile_bgra(*t), o.tile_bgra(*t)), t\n"
         "print('single band ok')\n"
     ) % (here, os.path.dirname(here))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1"}), capture_output=True, text=True, timeout=600)
+    exp = os.path.join(os.path.dirname(here), "pi-slam-fusion_amd", "libpifusion_exp.so")      # the switches exist in the experiments build only (csrc/env.hpp)
+    assert os.path.exists(exp), "build the experiments library first (__graft_entry__.build())"
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1", "PF_LIB": exp}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "single band ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -8,6 +8,7 @@ PF_CULL_MARGIN_PX / PF_CULL_MARGIN_W per setting, and every case is run once per
 against the oracle per setting -- is the measured safety factor of the defaults (profiles/r05_cull_margins.md).
 --steep N: N more cases from the steep-tilt generator (corner rays up to the 0.4 obliqueness gate)."""
 import os, sys
+os.environ.setdefault("PF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pi-slam-fusion_amd", "libpifusion_exp.so"))   # the switches below exist in the experiments build only (csrc/env.hpp)
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, R)
 from conftest import load_package

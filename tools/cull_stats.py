@@ -1,4 +1,5 @@
 import importlib, os, sys
+os.environ.setdefault("PF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pi-slam-fusion_amd", "libpifusion_exp.so"))   # the switches below exist in the experiments build only (csrc/env.hpp)
 sys.path.insert(0, os.getcwd())
 import bench, torch
 pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PF_LIB=${PF_LIB:-pi-slam-fusion_amd/libpifusion_exp.so}   # PF_SINGLE_STREAM exists in the experiments build only (csrc/env.hpp)
 # bash tools/per_level_traffic.sh <tag>  -> gpurun_out/per_level_<tag>.md   (one kernel per level: pf_options.fused = 3)
 export TMPDIR=/tmp
 tag=${1:-r03}; out=gpurun_out/per_level_$tag

@@ -19,11 +19,11 @@ import torch
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--int16", action="store_true"); ap.add_argument("--frames", type=int, default=200); ap.add_argument("--warm", type=int, default=20)
-ap.add_argument("--owner", default="hash", help="hash (the library's owner function) | cyclic (2-D block-cyclic, evaluation: sets PF_SHARD_OWNER)")
+ap.add_argument("--owner", default="hash", help="hash (the library's owner function) | cyclic (2-D block-cyclic, evaluation: experiments library, PF_SHARD_OWNER_CYCLIC)")
 ap.add_argument("--ranks", default="2,4,8"); ap.add_argument("--cells", default="2,4,8"); ap.add_argument("--md", default=None)
 a = ap.parse_args()
 if a.owner == "cyclic":
-    os.environ["PF_SHARD_OWNER"] = "cyclic"          # read once, when the library first asks for an owner
+    os.environ["PF_SHARD_OWNER_CYCLIC"] = "1"; os.environ.setdefault("PF_LIB", os.path.join(R, "pi-slam-fusion_amd", "libpifusion_exp.so"))   # experiments library; read once, when the library first asks for an owner
 pf = bench.load_package(); wl = importlib.import_module("pi_slam_fusion_amd.workloads")
 sh = importlib.import_module("pi_slam_fusion_amd.sharding")
 cam = bench.CAM
