@@ -95,7 +95,7 @@ inline bool read_ppm_bgr(const std::string& path, OwnedImage& out)
     FILE* f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     char magic[3] = { 0, 0, 0 };
-    int w = 0, h = 0, maxv = 0, got = 0;
+    int w = 0, h = 0, maxv = 0;
     auto next_int = [&](int& v) {
         int ch = std::fgetc(f);
         for (;;) {
@@ -105,15 +105,26 @@ inline bool read_ppm_bgr(const std::string& path, OwnedImage& out)
         }
         if (ch < '0' || ch > '9') return false;
         v = 0;
-        while (ch >= '0' && ch <= '9') { v = v * 10 + (ch - '0'); ch = std::fgetc(f); }
+        while (ch >= '0' && ch <= '9') {
+            if (v > (1 << 26)) return false;          // not a picture size (and the digit loop must not overflow)
+            v = v * 10 + (ch - '0'); ch = std::fgetc(f);
+        }
         return true;          // the single whitespace after the last header field has been consumed
     };
     bool ok = std::fread(magic, 1, 2, f) == 2 && magic[0] == 'P' && magic[1] == '6' && next_int(w) && next_int(h) && next_int(maxv) &&
-              w > 0 && h > 0 && maxv == 255;
+              w > 0 && h > 0 && maxv == 255 && (long long)w * h <= (1ll << 28);
+    if (ok) {
+        // the pixels must be in the file before memory is asked for them (a damaged header must not allocate gigabytes)
+        const long here = std::ftell(f);
+        std::fseek(f, 0, SEEK_END);
+        const long end = std::ftell(f);
+        std::fseek(f, here, SEEK_SET);
+        ok = here >= 0 && end - here >= (long)((size_t)w * h * 3);
+    }
     if (ok) {
         out.create(h, w, PF_8UC3);
-        got = (int)std::fread(out.data, 1, (size_t)w * h * 3, f);
-        ok = got == w * h * 3;
+        const size_t want = (size_t)w * h * 3, got_n = std::fread(out.data, 1, want, f);
+        ok = got_n == want;
         for (size_t i = 0; ok && i < (size_t)w * h; i++) std::swap(out.data[3 * i], out.data[3 * i + 2]);
     }
     std::fclose(f);
@@ -162,8 +173,9 @@ public:
         std::fseek(f, 0, SEEK_END);
         const long n = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
-        out.resize(n > 0 ? (size_t)n : 0);
-        const bool ok = n > 0 && std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+        const bool sane = n > 0 && n <= (1L << 31);                      // (a directory opens, and ftell() then says LONG_MAX)
+        out.resize(sane ? (size_t)n : 0);
+        const bool ok = sane && std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
         std::fclose(f);
         if (!ok) out.clear();
         return ok;

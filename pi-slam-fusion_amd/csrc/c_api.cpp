@@ -21,7 +21,13 @@ struct pf_map {
 
 // pf_jpeg_decode_device's decoder: process-wide, never torn down (the runtime may be gone at exit)
 static std::mutex g_jpeg_mu;
-static pf::JpegDevice* shared_jpeg() { static pf::JpegDevice* d = new pf::JpegDevice(); return d; }
+static pf::JpegDevice* shared_jpeg(int device = 0)          // one per device: its buffers live where the first call on that device put them
+{
+    static pf::JpegDevice* d[64] = {};
+    if (device < 0 || device >= 64) device = 0;
+    if (!d[device]) d[device] = new pf::JpegDevice();
+    return d[device];
+}
 
 extern "C" {
 
@@ -84,34 +90,23 @@ long pf_debug_read_last_frame(pf_map* m, void* out, size_t cap) { return m ? m->
 unsigned pf_queue_size(pf_map* m) { return m ? m->impl.queue_size() : 0; }
 int pf_sync(pf_map* m) { return m && m->impl.sync(); }
 int pf_save(pf_map* m, const char* filename) { return m && filename && m->impl.save(filename); }
-int pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols)
-{ return filename && bgr && rows > 0 && cols > 0 && pf::write_image_file(filename, bgr, rows, cols); }
-int pf_image_info(const char* filename, int* rows, int* cols)
-{
-    if (!filename || !rows || !cols) return 0;
-    std::vector<uint8_t> b;
-    if (!pf::read_file_bytes(filename, b)) return 0;
-    if (b.size() >= 2 && b[0] == 0xFF && b[1] == 0xD8) return pf::jpeg_info(b.data(), b.size(), rows, cols, nullptr);
-    if (b.size() >= 8 && b[0] == 0x89 && b[1] == 'P' && b[2] == 'N' && b[3] == 'G') return pf::png_info(b.data(), b.size(), rows, cols);
-    std::vector<uint8_t> px;                                                  // PPM: the header is all there is to parse
-    return pf::read_image_file(filename, px, rows, cols);
-}
-int pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols)
-{
-    if (!filename || !bgr) return 0;
-    std::vector<uint8_t> px; int r = 0, c = 0;
-    if (!pf::read_image_file(filename, px, &r, &c)) return 0;
-    if (r != rows || c != cols) { pf::set_error("pf_read_image: the buffer does not have the image's size"); return 0; }
-    std::memcpy(bgr, px.data(), px.size());
-    return 1;
-}
+// pf_write_image / pf_image_info / pf_read_image: image_io.cpp (host code without a HIP dependency: also built by the sanitizer targets)
 int pf_jpeg_info(const uint8_t* data, size_t len, int* rows, int* cols, int* components) { return pf::jpeg_info(data, len, rows, cols, components); }
 int pf_jpeg_decode_bgr(const uint8_t* data, size_t len, uint8_t* bgr, int rows, int cols)
 { return rows > 0 && cols > 0 && pf::jpeg_decode_bgr(data, len, bgr, rows, cols, (size_t)cols * 3); }
 int pf_jpeg_decode_device(const uint8_t* data, size_t len, void* dev_bgr, int rows, int cols, void* hip_stream)
 {
     std::lock_guard<std::mutex> l(g_jpeg_mu);
-    return rows > 0 && cols > 0 && shared_jpeg()->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
+    if (rows <= 0 || cols <= 0 || !dev_bgr) return 0;
+    // the decoder of the device the destination lives on, with that device current for the call
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, dev_bgr) != hipSuccess || at.type != hipMemoryTypeDevice) { (void)hipGetLastError(); pf::set_error("pf_jpeg_decode_device: destination is not device memory"); return 0; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (at.device != prev && hipSetDevice(at.device) != hipSuccess) { pf::set_error("pf_jpeg_decode_device: hipSetDevice failed"); return 0; }
+    const int ok = shared_jpeg(at.device)->decode_to(data, len, (uint8_t*)dev_bgr, rows, cols, hip_stream);
+    if (at.device != prev) (void)hipSetDevice(prev);
+    return ok;
 }
 void pf_debug_jpeg_huffman(pf_map* m, long long out[3])
 {

@@ -1,6 +1,7 @@
 // dist.hpp -- seam exchange of the tile-sharded mosaic (dist.cpp)
 #pragma once
 #include "fusion_map.hpp"
+#include "dist_plan.hpp"
 
 namespace pf {
 
@@ -19,16 +20,7 @@ bool rccl_unique_id(void* out128);
 Transport* make_rccl_transport(const void* id128, int rank, int nranks, int device);
 Transport* make_host_transport(int rank, int nranks, pf_exchange_fn fn, void* user);
 
-// plan of one draw() across ranks (dist.cpp, plan_blend)
-struct BlendPlan {
-    std::vector<size_t> send_bytes, recv_bytes;                       // per peer
-    std::vector<std::vector<FusionMap::StripReq>> send_req;           // per requesting peer: this rank's tile to pack, offset inside the peer's region
-    struct Want { int tile, j, peer; size_t off; };                   // this rank's tile `tile` (index in mine) gets neighbour j from peer
-    std::vector<Want> wants;
-    std::vector<std::pair<int, int>> mine;                            // this rank's changed tiles, in blend order, at most its cap
-};
-void plan_blend(const std::vector<std::vector<FusionMap::TileRec>>& all, const std::vector<long long>& caps, int me, bool hq,
-                const size_t halo_bytes9[9], BlendPlan& out);
+// BlendPlan, plan_blend: dist_plan.hpp
 
 class DistMap {
 public:

@@ -4,6 +4,7 @@
 #include "../../include/pifusion.h"
 #include "geometry.hpp"
 #include "kernels.hpp"
+#include "dist_plan.hpp"
 #include "env.hpp"
 #include <hip/hip_runtime.h>
 #include <condition_variable>
@@ -108,8 +109,8 @@ public:
     bool save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0, const std::vector<ForeignTile>* foreign = nullptr);
 
     // seam exchange support (dist.cpp)
-    struct TileRec  { int ix, iy, changed; };
-    struct StripReq { int ix, iy, dx, dy; size_t out_off; };      // tile (ix,iy) of THIS rank hands its edge facing (-dx,-dy)... see pf_halo_pack
+    using TileRec = pf::TileRec;        // dist_plan.hpp
+    using StripReq = pf::StripReq;
     void list_tiles(std::vector<TileRec>& out);
     bool pack_strips(const std::vector<StripReq>& reqs, void* dev_out);
     bool export_tiles(const std::vector<std::pair<int, int>>& tiles, void* dev_out);

@@ -1,13 +1,16 @@
 // image_io.cpp -- output side of save(): the reference hands the mosaic to
 // cv::imwrite (MultiBandMap2DCPU.cpp:841).  PNG (8-bit RGB, zlib stream split
 // over IDAT chunks) when the name ends in .png, binary PPM otherwise.
-#include "fusion_map.hpp"
+#include "../../include/pifusion.h"
+#include "jpeg_decode.hpp"
 #include <cstdio>
 #include <cstring>
 #include <vector>
 #include <zlib.h>
 
 namespace pf {
+
+bool write_image_file(const char* filename, const uint8_t* bgr, int rows, int cols);      // also declared in fusion_map.hpp (save())
 
 static void put_be32(uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
 
@@ -74,3 +77,28 @@ bool write_image_file(const char* filename, const uint8_t* bgr, int rows, int co
 }
 
 }  // namespace pf
+
+// the C ABI of the image files (include/pifusion.h): cv::imwrite / cv::imread of the file driver
+extern "C" {
+int pf_write_image(const char* filename, const uint8_t* bgr, int rows, int cols)
+{ return filename && bgr && rows > 0 && cols > 0 && pf::write_image_file(filename, bgr, rows, cols); }
+int pf_image_info(const char* filename, int* rows, int* cols)
+{
+    if (!filename || !rows || !cols) return 0;
+    std::vector<uint8_t> b;
+    if (!pf::read_file_bytes(filename, b)) return 0;
+    if (b.size() >= 2 && b[0] == 0xFF && b[1] == 0xD8) return pf::jpeg_info(b.data(), b.size(), rows, cols, nullptr);
+    if (b.size() >= 8 && b[0] == 0x89 && b[1] == 'P' && b[2] == 'N' && b[3] == 'G') return pf::png_info(b.data(), b.size(), rows, cols);
+    std::vector<uint8_t> px;                                                  // PPM: the header is all there is to parse
+    return pf::read_image_file(filename, px, rows, cols);
+}
+int pf_read_image(const char* filename, uint8_t* bgr, int rows, int cols)
+{
+    if (!filename || !bgr) return 0;
+    std::vector<uint8_t> px; int r = 0, c = 0;
+    if (!pf::read_image_file(filename, px, &r, &c)) return 0;
+    if (r != rows || c != cols) { pf::set_error("pf_read_image: the buffer does not have the image's size"); return 0; }
+    std::memcpy(bgr, px.data(), px.size());
+    return 1;
+}
+}  // extern "C"

@@ -528,15 +528,18 @@ struct Decoder {
     bool output_bgr(uint8_t* out, size_t stride)
     {
         // jdcolor.c build_ycc_rgb_table, SCALEBITS 16
-        static int crr[256], cbb[256], crg[256], cbg[256]; static bool tab = false;
-        if (!tab) {
-            for (int i = 0; i < 256; i++) {
-                const int x = i - 128;
-                crr[i] = (91881 * x + 32768) >> 16; cbb[i] = (116130 * x + 32768) >> 16;
-                crg[i] = -46802 * x; cbg[i] = -22554 * x + 32768;
+        struct Tables {
+            int crr[256], cbb[256], crg[256], cbg[256];
+            Tables() {
+                for (int i = 0; i < 256; i++) {
+                    const int x = i - 128;
+                    crr[i] = (91881 * x + 32768) >> 16; cbb[i] = (116130 * x + 32768) >> 16;
+                    crg[i] = -46802 * x; cbg[i] = -22554 * x + 32768;
+                }
             }
-            tab = true;
-        }
+        };
+        static const Tables tb;                                   // built once, thread-safe (callers decode on several threads)
+        const int* const crr = tb.crr; const int* const cbb = tb.cbb; const int* const crg = tb.crg; const int* const cbg = tb.cbg;
         const bool ycc = is_ycc();
         const size_t lw = (size_t)mcux * hmax * 8 + 8;
         std::vector<uint8_t> l0(lw), l1(lw), l2(lw);
@@ -735,8 +738,10 @@ bool read_file_bytes(const char* filename, std::vector<uint8_t>& out)
     std::fseek(f, 0, SEEK_END);
     const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
-    out.resize(sz > 0 ? (size_t)sz : 0);
-    const bool ok = sz > 0 && std::fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+    // (a directory opens, and ftell() then says LONG_MAX: nothing that is not a file of at most 2 GiB is an image cv::imread takes)
+    const bool sane = sz > 0 && sz <= (1L << 31);
+    out.resize(sane ? (size_t)sz : 0);
+    const bool ok = sane && std::fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
     std::fclose(f);
     if (!ok) set_error(std::string("cannot read ") + filename);
     return ok;
@@ -759,11 +764,15 @@ static bool ppm_header(const std::vector<uint8_t>& b, int& w, int& h, size_t& at
         }
         if (at >= b.size() || b[at] < '0' || b[at] > '9') return false;
         v[i] = 0;
-        while (at < b.size() && b[at] >= '0' && b[at] <= '9') v[i] = v[i] * 10 + (b[at++] - '0');
+        while (at < b.size() && b[at] >= '0' && b[at] <= '9') {
+            if (v[i] > (1 << 26)) return false;          // no header field of a picture cv::imread takes is that large (and the digit loop must not overflow)
+            v[i] = v[i] * 10 + (b[at++] - '0');
+        }
     }
-    at++;                                             // the single whitespace after maxval
+    if (at >= b.size()) return false;                 // the header ends inside the file: ...
+    at++;                                             // ... the single whitespace after maxval, then the pixels (at <= size: the caller subtracts)
     w = v[0]; h = v[1];
-    return w > 0 && h > 0 && v[2] == 255;
+    return w > 0 && h > 0 && v[2] == 255 && (long long)w * h <= (1ll << 30);
 }
 
 // cv::imread(filename) for the formats the file driver feeds from: JPEG (by its SOI), PNG (by its signature) and binary PPM

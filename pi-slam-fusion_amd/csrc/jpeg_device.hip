@@ -292,7 +292,6 @@ __device__ inline void huff_stage(const HuffParPlan* __restrict__ P, const uint3
 // subsequence as the previous launch left it).  changed[r] is raised when a subsequence's result moves during launch r: a launch that raises
 // nothing is the fixed point.
 constexpr int kSweeps = 8;                    // measured: 4 / 8 / 16 sweeps per launch = 629 / 600 / 694 us of rounds per 12 MP 4:2:0 frame
-constexpr int kMaxLaunches = 64;              // 512 sweeps: a stream that has not settled by then goes to the host's serial pass
 template <bool RST>
 __global__ __launch_bounds__(256) void k_huff_round(const HuffParPlan* __restrict__ P, const uint32_t* __restrict__ words, const HuffParState* __restrict__ in,
                                                      HuffParState* __restrict__ out, HuffParState* __restrict__ used, uint32_t* __restrict__ nblk,
@@ -481,8 +480,11 @@ bool JpegDevice::entropy(int i, const uint8_t* data, size_t len)
 {
     Slot& s = slot_[i];
     static const bool host_huffman = exp_env("PF_JPEG_HOST_HUFFMAN") != nullptr;         // experiments library (A/B, tests): the serial pass on the host for every stream
-    if (!host_huffman && skip_par_ > 0) skip_par_--;            // a recent stream of this consumer did not settle: its neighbours will not either
-    else if (!host_huffman) {
+    // a recent stream of this consumer did not settle: its neighbours will not either (several host threads come here in a batch: the counter
+    // is taken down by compare-exchange, never below zero)
+    bool skip = false;
+    for (int v = skip_par_.load(std::memory_order_relaxed); v > 0 && !skip; ) skip = skip_par_.compare_exchange_weak(v, v - 1, std::memory_order_relaxed);
+    if (!host_huffman && !skip) {
         // a stream the parallel pass takes: its scan's bytes (stuffing removed) and the plan go to the GPU, nothing else happens here
         HuffParPlan* plan = (HuffParPlan*)((char*)s.host + kHeaderBytes);
         uint8_t* bits = (uint8_t*)s.host + kHeaderBytes + kPlanBytes;
@@ -557,8 +559,9 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
     // synchronisation, a launch past the fixed point costs little: no workgroup has work).  Consecutive keyframes of a camera settle after about
     // the same number of launches: the first group is the previous frame's count plus one, the following groups two launches each.
     int cur = 0, round = 0; bool settled = S == 1;
-    int group = std::min(std::max(settle_hint_ + 1, 2), (int)kMaxRounds - 1);
-    while (!settled && round + group < kMaxLaunches) {
+    int group = std::max(settle_hint_ + 1, 2);
+    while (!settled && round < (int)kMaxRounds - 1) {
+        group = std::min(group, (int)kMaxRounds - 1 - round);          // never past the flags array, and a late settler cannot switch the loop off for its successors
         for (int r = 0; r < group; r++) {
             round++;
             if (rst) hipLaunchKernelGGL((k_huff_round<true>), grid, dim3(256), 0, st, P, words, (const HuffParState*)stt[cur], stt[cur ^ 1], used, nblk, changed, round, seg_end, seg_hint);
@@ -572,7 +575,7 @@ bool JpegDevice::huffman_on_device(int i, void* stream, size_t coef_bytes)
         group = 2;
     }
     last_rounds_ = round;
-    if (!settled) { skip_par_ = 15; return false; }          // (streams of quality 99 noise do this: ~250 rounds are 11 ms thrown away)
+    if (!settled) { skip_par_.store(15, std::memory_order_relaxed); settle_hint_ = 4; return false; }          // (streams of quality 99 noise do this: ~250 rounds are 11 ms thrown away)
     int16_t* dcoef = (int16_t*)((char*)dev_ + kHeaderBytes);
     const int tiles_s = (int)((S + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL((k_scan_totals<0>), dim3((unsigned)tiles_s, 1), dim3(256), 0, st, P, (const uint32_t*)nblk, (const int16_t*)dcoef, totals, stride);

@@ -1,5 +1,6 @@
 // jpeg_device.hpp -- device back end of the file driver's JPEG decode (jpeg_device.hip)
 #pragma once
+#include <atomic>
 #include "jpeg_decode.hpp"
 
 namespace pf {
@@ -32,7 +33,7 @@ private:
         const uint8_t* data = nullptr; size_t len = 0;        // the stream (the caller's, valid until submit): a fallback decodes it again
         bool par = false; size_t par_bytes = 0, aux_words = 0;   // staged for the Huffman pass on the GPU: the scan's bytes (stuffing removed), restart tables
     };
-    enum { kMaxRounds = 256 };
+    enum { kMaxRounds = 64 };     // launches of the round kernel (512 sweeps): the flags array and the launch limit; a stream that has not settled by then goes to the host's serial pass
     bool huffman_on_device(int i, void* stream, size_t coef_bytes);
     bool prepare(int i, const uint8_t* data, size_t len, int rows, int cols);
     bool entropy(int i, const uint8_t* data, size_t len);
@@ -43,7 +44,8 @@ private:
     Bytes  last_ = { 0, 0, 0 };
     void*  huff_ = nullptr;   size_t huff_cap_ = 0;          // plan, scan bytes, subsequence states and counts of the parallel Huffman pass
     void*  res_host_ = nullptr;
-    int    last_rounds_ = 0, settle_hint_ = 4, skip_par_ = 0; long par_frames_ = 0, fallback_frames_ = 0;
+    int    last_rounds_ = 0, settle_hint_ = 4; long par_frames_ = 0, fallback_frames_ = 0;
+    std::atomic<int> skip_par_{ 0 };      // entropy() runs on several host threads in a batch
 };
 
 }  // namespace pf

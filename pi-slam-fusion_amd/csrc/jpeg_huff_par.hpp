@@ -193,10 +193,15 @@ PF_HD bool huff_par_write(const HuffParPlan& P, const HuffParTable* __restrict__
     if (RST && p < limit) huff_par_seg_find(seg_end, seg_hint, p, sg, B);
     while (p < limit && g < total) {
         int wpos, value; bool done;
+        const int c0 = c, k0 = k;
         huff_par_step(ctl, tabs, words, bit0, p, c, k, wpos, value, done);
         if (RST && p > B) {                                   // padding at the end of the segment: nothing to write, the next segment starts over
             p = B; c = 0; k = 0; done = false; wpos = -1;
-            if (g != (sg + 1) * P.rst_blocks && bad) *bad = 1u;
+            // The symbol that crossed the end must have started on a block boundary with every block of the interval done.  A damaged
+            // segment that finishes its blocks a byte early would otherwise have its leftover bits decoded as the DC and a few AC symbols
+            // of a partial block and WRITTEN into the next interval's first block (the serial pass, like libjpeg, discards them at the
+            // restart): such a stream goes to the serial pass.
+            if ((g != (sg + 1) * P.rst_blocks || c0 != 0 || k0 != 0) && bad) *bad = 1u;
             if (g < total) base = huff_par_block_base(P, g / (uint32_t)P.bpm, 0);
             if (p < P.nbits) { sg++; B = seg_end[sg]; }
             continue;
