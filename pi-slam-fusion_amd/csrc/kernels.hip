@@ -738,11 +738,23 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int LAWH = (LAW + 1) / 2;                     // columns of one parity in the split layout
 
 // SPLIT: A is stored as [row][column parity][column / 2] (see level3_block)
-template <bool F32, int LAH, int LNT, bool SPLIT = false>
-__device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, const PxT<F32>* __restrict__ gin,
-                                               int ax0, int ay0, int rows, int cols, int tid, int begin = 0)
+template <bool F32, int LAH, int LNT, bool SPLIT = false, int PITCH = 2 * LAWH>
+__device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, const PxT<F32>* __restrict__ gin_,
+                                               int ax0, int ay0, int rows, int cols, int tid, int begin = 0, bool gw8 = false)
 {
     using Px = PxT<F32>;
+    // gw8 (experiments library, PF_ABLATE bit 4096, int16, TIMING ONLY -- wrong weights): GW records of 8 bytes at an 8-byte pitch, the bound of
+    // what a smaller int16 GW record (10 bytes in two planes) could gain (profiles/r06_ab.md)
+    struct Gin {
+        const PxT<F32>* p; bool g8;
+        __device__ __forceinline__ Px operator[](long a) const {
+            if constexpr (!F32 && kExp) {
+                if (g8) { typedef uint32_t u2g __attribute__((ext_vector_type(2))); const u2g v = ((const u2g*)p)[a]; Px o; __builtin_memcpy(&o, &v, 8); o.w = 0.5f; return o; }
+            }
+            return p[a];
+        }
+    };
+    const Gin gin{ gin_, gw8 };
     auto gaddr = [&](int idx) {
         idx = idx < LAH * LAW ? idx : tid;
         const int r = idx / LAW, c = idx - r * LAW;
@@ -752,7 +764,7 @@ __device__ __forceinline__ void stage_from_hbm(PxT<F32>* __restrict__ Aflat, con
     auto laddr = [&](int idx) {
         if (!SPLIT) return idx;
         const int r = idx / LAW, c = idx - r * LAW;
-        return r * (2 * LAWH) + (c & 1) * LAWH + (c >> 1);
+        return r * PITCH + (c & 1) * LAWH + (c >> 1);
     };
     if constexpr (SPLIT && LAH * LAW <= 6 * LNT) {
         // the whole tile in one round: six loads per thread in flight before the first LDS store.  These workgroups do
@@ -1027,17 +1039,21 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
     struct Bx { T c[F32 ? 3 : 4]; };                            // stage D needs G_{i+1} only, not W_{i+1}
     // A is split by column parity, [row][parity][column / 2]: the pyrDown taps of neighbouring threads (2q .. 2q+4)
     // and the 2x2 quads of stage D are then 16 bytes apart per lane instead of 32 -- no LDS bank conflicts
-    __shared__ Px A[LAH][2][LAWH];
+    // (LBH == 24, experiments library: the odd columns follow the 36 even ones without the padding column -- 71 pixels per row, so that a 64 x 24
+    // fp32 block takes 40 928 bytes with Bt and FOUR workgroups share a CU's 160 KB)
+    constexpr int kPitch = LBH == 24 ? LAW : 2 * LAWH;
+    __shared__ Px A[LAH][kPitch];
     // Bt (stage B -> D) and, in a PATCH kernel, the source patch of stage A share the LDS behind A: the patch is dead at
     // the barrier that ends stage A, Bt is first written after it
     constexpr int kTail = PATCH ? kPatchBytes : (int)(sizeof(Bx) * LQH * LQW);
     static_assert(kTail >= (int)(sizeof(Bx) * LQH * LQW), "Bt must fit");
     __shared__ __attribute__((aligned(16))) unsigned char tail[kTail];
     Bx (*Bt)[LQW] = reinterpret_cast<Bx (*)[LQW]>(tail);
-    auto Aat = [&](int r, int c) -> Px& { return A[r][c & 1][c >> 1]; };
+    auto Aat = [&](int r, int c) -> Px& { return A[r][(c & 1) * LAWH + (c >> 1)]; };
     // LDS is allocated in 1280-byte granules on gfx950: fp32 must stay under 42 granules for three
     // workgroups per CU, int16 under 32 for four
     static_assert(LBH != 32 || PATCH || sizeof(A) + sizeof(tail) <= (F32 ? 42 : 32) * 1280, "LDS budget (64x32 blocks)");
+    static_assert(LBH != 24 || sizeof(A) + sizeof(tail) <= 32 * 1280, "LDS budget (64x24 blocks: four workgroups per CU for both pyramid types)");
     static_assert(LBH != 32 || !PATCH || sizeof(A) + sizeof(tail) <= 64 * 1280, "LDS budget (64x32 blocks with a source patch: two per CU)");
     static_assert(LBH != 64 || sizeof(A) + sizeof(tail) <= (F32 ? 128 : 64) * 1280, "LDS budget (64x64 blocks of 1024 threads: int16 two per CU, fp32 one)");
 
@@ -1249,7 +1265,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                 const int cn = wa.cn, sstep = wa.sstep;
                 // All NR rows of a thread at once (fp32), or in two halves (int16: twelve dwords of row data instead of twenty-four keep the kernel
                 // inside the 64 VGPRs of four workgroups per CU)
-                constexpr int CH = F32 ? NR : (NR + 1) / 2;
+                constexpr int CH = (F32 && LBH != 24) ? NR : (NR + 1) / 2;      // (64 x 24 fp32 blocks, experiments library: halves as well -- 64 VGPRs for a fourth workgroup per CU)
                 u2 b0[CH], b1[CH];
                 float wq[(CH + 1) / 2] = {};                       // gathered weights (A/B, see below): kept in registers until the finish
                 // A thread's rows are CONSECUTIVE (r0 * NR + k).  (Experiments build, PF_SEED=1: the reciprocal of row k + 1 starts from that of
@@ -1351,7 +1367,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
             }
         }
     } else {
-        stage_from_hbm<F32, LAH, LNT, true>(&A[0][0][0], gw_in, ax0, ay0, g.rows, g.cols, tid);
+        stage_from_hbm<F32, LAH, LNT, true, kPitch>(&A[0][0], gw_in, ax0, ay0, g.rows, g.cols, tid, 0, kExp && !F32 && (g.ablate & 4096));
     }
     if (STAMP) phase_stamp(stamps, 1);
     if (kExp && FROM_WARP && (g.ablate & (1024 | 2048))) __builtin_amdgcn_s_setprio(0);
@@ -1443,7 +1459,7 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
             };
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                const f4* ev = (const f4*)&A[4 * pp + j][0][q]; const f4* od = (const f4*)&A[4 * pp + j][1][q];
+                const f4* ev = (const f4*)&A[4 * pp + j][q]; const f4* od = (const f4*)&A[4 * pp + j][LAWH + q];
                 const f4 a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
                 hl[j] = a2.xy * 6.f + (a1.xy + a3.xy) * 4.f + a0.xy + a4.xy;
                 hh[j] = a2.zw * 6.f + (a1.zw + a3.zw) * 4.f + a0.zw + a4.zw;
@@ -1479,13 +1495,18 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
                     Bt[p][q] = ob;
                 }
                 if (p >= 1 && p < LQH - 1 && q >= 1 && q < LQW - 1) {      // this block's own part of level i+1
+                    if (kExp && (g.ablate & 4096)) {                          // timing only: 8-byte GW records (see stage_from_hbm)
+                        typedef uint32_t u2g __attribute__((ext_vector_type(2)));
+                        u2g v; __builtin_memcpy(&v, &o, 8);
+                        if (g.write_next) ((u2g*)gw_out)[(long)Y * ncols + X] = v;
+                    } else
                     if (g.write_next) gw_out[(long)Y * ncols + X] = o;
                     if (g.top_select) select_store<F32>(lay.top_lap_off, lay.top_w_off, g.level + 1, table, g.tiles_x, X, Y, o.c, o.w);
                 }
             };
 #pragma unroll
             for (int j = 0; j < 7; j++) {
-                const PxP* ev = reinterpret_cast<const PxP*>(&A[4 * pp + j][0][q]); const PxP* od = reinterpret_cast<const PxP*>(&A[4 * pp + j][1][q]);
+                const PxP* ev = reinterpret_cast<const PxP*>(&A[4 * pp + j][q]); const PxP* od = reinterpret_cast<const PxP*>(&A[4 * pp + j][LAWH + q]);
                 const PxP a0 = ev[0], a1 = od[0], a2 = ev[1], a3 = od[1], a4 = ev[2];
                 h01[j] = a2.c01 * (us2)6 + (a1.c01 + a3.c01) * (us2)4 + a0.c01 + a4.c01;
                 h2p[j] = a2.c2p * (us2)6 + (a1.c2p + a3.c2p) * (us2)4 + a0.c2p + a4.c2p;
@@ -1506,8 +1527,8 @@ __device__ __forceinline__ void level3_block(const bool FROM_WARP, const LO& lay
     int ry = dy0;                                                // the quad's row in A from dy0 (live anyway), not from a register kept since the top
     asm volatile("" : "+v"(ry));
     ry -= y0;
-    const Px g00 = A[ry + 4][0][qx + 2], g01 = A[ry + 4][1][qx + 2];
-    const Px g10 = A[ry + 5][0][qx + 2], g11 = A[ry + 5][1][qx + 2];
+    const Px g00 = A[ry + 4][qx + 2], g01 = A[ry + 4][LAWH + qx + 2];
+    const Px g10 = A[ry + 5][qx + 2], g11 = A[ry + 5][LAWH + qx + 2];
     const bool in01 = dx0 + 1 < g.cols, in10 = dy0 + 1 < g.rows;
     const bool s00 = g00.w >= dwv[0][0], s01 = in01 && g01.w >= dwv[0][1];
     const bool s10 = in10 && g10.w >= dwv[1][0], s11 = in10 && in01 && g11.w >= dwv[1][1];
@@ -1688,7 +1709,7 @@ static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 2 * sizeof(void*) <= 4096
 static_assert(sizeof(LevelBatch) + sizeof(FusedWarp) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 template <bool F32, int LBH, int LNT, bool STAMP = false, int ILP = 2, bool PATCH = false, bool WA = false>
-__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((!F32 && (ILP == 2 || ILP == 0)) ? 8 : 6) : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
+__global__ __launch_bounds__(LNT, (LNT == 512 && !PATCH) ? ((LBH == 24 || (!F32 && (ILP == 2 || ILP == 0))) ? 8 : 6) : 4) void k_levels(LevelBatch batch, FusedWarp wa, const uint8_t* __restrict__ src, unsigned long long* stamps)
 {
     // Block ids are dealt in groups of 8 (one per XCD).  Group g belongs to the FIRST job (level 0 of the newest frame
     // when there is one) or to the upper-level jobs: last in the grid by default, or (PF_INTERLEAVE_JOBS, diagnostics)
@@ -2081,7 +2102,8 @@ int level0_need_reach(const TileLayout& lay, int table_n, int nrect0)
 {
     static const bool off = kExp && getenv("PF_NO_NEED_R0") != nullptr;                                 // A/B: the need rectangles for job 0 too
     static const bool strips = kExp && getenv("PF_STRIPS") && atoi(getenv("PF_STRIPS")) != 0;             // the strip form keeps the rectangles
-    if (off || strips || table_n <= 0 || table_n > kArgTable || nrect0 <= 0 || level_block_rows(lay.f32 != 0) != 32) return 0;
+    const int bh = level_block_rows(lay.f32 != 0);
+    if (off || strips || table_n <= 0 || table_n > kArgTable || nrect0 <= 0 || !(bh == 32 || (kExp && bh == 24))) return 0;
     const int r0 = 3 * (1 << (lay.nlev - 1)) - 2;
     return r0 <= 96 ? r0 : 0;                                     // beyond five bands the reach spans more than two tiles: the rectangles
 }
@@ -2170,6 +2192,15 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
         batch.rect_runs = rect_runs;
     }
     if (batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0) batch.need_r0 = level0_need_reach(lay, batch.tab0_n, batch.job[0].nrect);
+#if PF_EXPERIMENTS
+    // A/B (PF_FORCE_NEED_TEST=1, with PF_CULL=0): every level-0 block runs its need test although nothing is culled -- the test is then always
+    // true and the work the same as without it: what the test costs a launch, i.e. the most a host-side level-0 bitmap could save (profiles/r06_ab.md)
+    static const bool force_test = getenv("PF_FORCE_NEED_TEST") != nullptr;
+    if (force_test && batch.njobs && batch.job[0].from_warp && batch.job[0].g.level == 0 && batch.tab0_n > 0 && batch.job[0].nrect == 0 && !batch.need_r0) {
+        batch.need_r0 = level0_need_reach(lay, batch.tab0_n, 1);
+        if (batch.need_r0) { batch.job[0].nrect = 1; batch.rect0[0] = BlockRect{ 0, 0, 32767, 32767 }; }
+    }
+#endif
     if (!batch.njobs) return;
     FusedWarp w{};
     if (wa) {
@@ -2215,6 +2246,11 @@ void launch_levels(hipStream_t s, const TileLayout& lay, const LevelLaunch* jobs
     if (wa && batch.job[0].from_warp && patch_plan(*wa, batch.job[0].g.rows, batch.job[0].g.cols, BH, w)) {
         g_form_counts[2]++;
         if (lay.f32) PF_GO(true, 32, 512, false, 2, true, false); else PF_GO(false, 32, 512, false, 2, true, false);
+        return;
+    }
+    if (BH == 24) {                                   // PF_BLOCK24 (A/B, profiles/r06_ab.md): 64 x 24 blocks, 40 928 B of LDS and 64 VGPRs -> four workgroups per CU for fp32 too
+        if (wa) g_form_counts[5]++;
+        if (lay.f32) PF_GO(true, 24, 512, false, 0, false, true); else PF_GO(false, 24, 512, false, 2, false, true);
         return;
     }
     if (BH == 28) {                                   // PF_BLOCK28 (A/B): 64x28 blocks stage 35 rows = five whole passes of the 7 rows 512 threads warp at a time
@@ -2264,8 +2300,8 @@ int level_block_rows(bool f32)
 {
     (void)f32;
 #if PF_EXPERIMENTS
-    static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr;
-    return b64 ? 64 : (b28 ? 28 : 32);
+    static const bool b64 = getenv("PF_BLOCK64") != nullptr, b28 = getenv("PF_BLOCK28") != nullptr, b24 = getenv("PF_BLOCK24") != nullptr;
+    return b64 ? 64 : (b28 ? 28 : (b24 ? 24 : 32));
 #else
     return 32;
 #endif

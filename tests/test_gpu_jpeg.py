@@ -271,3 +271,28 @@ def test_restart_interval_streams_on_the_gpu(pf):
         mid += 1
     s[mid] ^= 0x5A
     assert np.array_equal(on_device(pf, bytes(s)), pf.decode_jpeg(bytes(s)))
+    # ... and a seeded sweep of bit flips inside the segments of restart-interval streams (a damaged segment that finishes its blocks
+    # early left bits which the parallel write pass decoded into the NEXT interval's first block and still accepted the stream; the host
+    # simulation finds 3 such streams in ~700, tests/test_sanitizers.py): whatever both decoders accept, they decode alike
+    rng = np.random.default_rng(20261005)
+    bases = []
+    for (h, w, q, sub, kw) in [(96, 128, 60, 2, {"restart_marker_blocks": 2}), (120, 160, 85, 0, {"restart_marker_rows": 1}), (64, 200, 92, 1, {"restart_marker_blocks": 5})]:
+        b = io.BytesIO(); Image.fromarray(picture(h, w, h + w)).save(b, "JPEG", quality=q, subsampling=sub, **kw); bases.append(b.getvalue())
+    both = refused = 0
+    for it in range(360):
+        s = bytearray(bases[it % 3]); lo = s.index(b"\xff\xda") + 14
+        for _ in range(int(rng.integers(1, 3))):
+            at = int(rng.integers(lo, len(s) - 2))
+            if s[at] == 0xFF or s[at - 1] == 0xFF:
+                continue                                               # markers and stuffing stay: the damage is to the entropy-coded bits
+            s[at] ^= 1 << int(rng.integers(8))
+            if s[at] == 0xFF:
+                s[at] = 0xFE
+        try:
+            want = pf.decode_jpeg(bytes(s))
+        except ValueError:
+            refused += 1
+            continue
+        assert np.array_equal(on_device(pf, bytes(s)), want), it
+        both += 1
+    assert both > 250

@@ -6,6 +6,7 @@ tests in a child process (the switches are read once per process):
   PF_A_ILP=2 / 3     two / three warp rows per step for both pyramid types (defaults: fp32 3, int16 2)
   PF_STRIPS=1        the wave-specialised rolling-strip form (profiles/r04_strips.md)
   PF_BLOCK28=1       64x28 blocks
+  PF_BLOCK24=1       64x24 blocks with the unpadded 71-pixel LDS pitch: 40 928 B and 64 VGPRs, four workgroups per CU for fp32 too (profiles/r06_ab.md)
   PF_A_ILP=0         int16: stage A with deferred finishes (fp32's product form)
   PF_SEED=1          fp32: the reciprocal of a pixel's W seeded from the row above (kernels.hip rcp_seeded)
   PF_COMPACT=1       a shard's level-0 job on the compact grid (one workgroup per block inside its need rectangles)
@@ -29,9 +30,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # fall-back to the default form
 EXP_LIB = os.path.join(ROOT, "pi-slam-fusion_amd", "libpifusion_exp.so")
 # every switch but PF_CULL (a documented runtime option of the product library, csrc/env.hpp) exists in the experiments library only
-NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28", "PF_SEED", "PF_COMPACT", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_CULL_SUB"}
+NEEDS_EXP = {"PF_PATCH", "PF_A_ILP", "PF_STRIPS", "PF_BLOCK28", "PF_BLOCK24", "PF_SEED", "PF_COMPACT", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_CULL_SUB"}
 FORM = {"PF_PATCH": "c[2] > 0", "PF_WEIGHT_PLANE": "c[1] > 0 and c[0] == 0", "PF_TABLE_COPY": "c[7] == 0 and c[0] > 0",
-        "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_A_ILP=0": "c[0] > 0", "PF_SEED": "c[0] > 0", "PF_COMPACT": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0",
+        "PF_A_ILP=2": "c[0] > 0", "PF_A_ILP=3": "c[0] > 0", "PF_A_ILP=0": "c[0] > 0", "PF_SEED": "c[0] > 0", "PF_COMPACT": "c[0] > 0", "PF_STRIPS": "c[3] > 0 and c[0] == 0", "PF_BLOCK28": "c[5] > 0 and c[0] == 0", "PF_BLOCK24": "c[5] > 0 and c[0] == 0",
         "PF_CULL=0": "culled == 0 and c[0] > 0", "PF_CULL_SUB=2": "culled > 0 and g.culled_cells() % 4 == 0 and c[0] > 0"}
 PROBE = """
 import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -53,7 +54,7 @@ assert %s, (c, culled)
 """
 
 
-@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_A_ILP=0", "PF_SEED", "PF_COMPACT", "PF_STRIPS", "PF_BLOCK28",
+@pytest.mark.parametrize("switch", ["PF_PATCH", "PF_WEIGHT_PLANE", "PF_TABLE_COPY", "PF_A_ILP=2", "PF_A_ILP=3", "PF_A_ILP=0", "PF_SEED", "PF_COMPACT", "PF_STRIPS", "PF_BLOCK28", "PF_BLOCK24",
                                     "PF_CULL=0", "PF_CULL_SUB=2"])
 def test_variant_equals_oracle(switch):
     name, _, val = switch.partition("=")
