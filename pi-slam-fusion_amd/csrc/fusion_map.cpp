@@ -805,11 +805,16 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
     const int tx = w.tx, ty = w.ty, L = w.L;
     w.sharded = opt_.shard_count > 1;
     const bool sharded = w.sharded;
-    w.cull = cull_on_ && !single_band_ && opt_.fused == 1 && L >= 1 && invert3x3(w.M0, w.Minv) && cull_frame_ok(w.Minv, w.crows, w.ccols);
+    w.cull = cull_on_ && (single_band_ || (opt_.fused == 1 && L >= 1)) && invert3x3(w.M0, w.Minv) && cull_frame_ok(w.Minv, w.crows, w.ccols);
     const bool cull = w.cull;
     const int S = cull_sub_, span = 4 / S;                       // cells per tile edge; lattice steps per cell
     if (cull) w.raise.reserve((size_t)tx * ty * S * S);
-    if (cull) cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, ((2 << L) - 2 + 63) / 64);
+    // Map2DCPU (single band, round 6): no pyramid, so a cell is not dilated; the bounds are those of the radial weight all the same, compared
+    // three alpha steps apart -- the stored alpha byte is floor(254 w) (at least 2) interpolated with 15-bit taps (within 1 of its smallest
+    // tap), the select is `ele.a < dst.a` (Map2DCPU.cpp:326-327): the keyframe cannot win where 254 wmax <= 254 wlb - 3.
+    if (cull) cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << L) - 2 + 63) / 64);
+    const float sb_gap = single_band_ ? 3.2f / 254.f : 0.f, sb_floor = single_band_ ? 6.f / 254.f : 0.f;
+    auto stored_bound = [&](float wlb) { return wlb > sb_floor ? wlb - sb_gap : 0.f; };      // what cell_out compares the keyframe's weights with
     const int B = opt_.shard_block;
     // cells of the need rectangles: a shard's hash cells; for the cull alone squares of 8 x 8 tiles as well (experiments library: PF_CULL_CELL)
     static const int bc_env = exp_env_int("PF_CULL_CELL", 0);
@@ -850,12 +855,12 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
                     if (!t->fresh) {
                         float wl = t->wlb[0], unused;
                         for (int q = 1; q < S * S; q++) wl = std::min(wl, t->wlb[q]);
-                        tile_out = cell_out(4 * x, 4 * y, 4, opt_.weight_type, wl, true, &unused);
+                        tile_out = cell_out(4 * x, 4 * y, 4, opt_.weight_type, stored_bound(wl), true, &unused);
                     }
                     for (int q = 0; q < S * S; q++) {
                         const int qx = q % S, qy = q / S;
                         float wmin;
-                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, t->wlb[q], !t->fresh && !tile_out, &wmin) || tile_out)
+                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, stored_bound(t->wlb[q]), !t->fresh && !tile_out, &wmin) || tile_out)
                             out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
                         if (wmin > t->wlb[q]) w.raise.push_back(FrameWork::Raise{ t, q, wmin });
                     }

@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void k_single(const uint8_t* __restrict__ src,
     const int xb = a.x_off + blockIdx.x * 64;
     const int y  = a.y_off + blockIdx.y * 4 + wave;
     const int x  = xb + lane;
-    const uint64_t ent = table[(y >> 8) * tiles_x + (x >> 8)];
+    uint64_t ent = table[(y >> 8) * tiles_x + (x >> 8)];
     if (!ent) return;
+    if ((ent >> (48 + ((y >> 6) & 3) * 4 + ((xb >> 6) & 3))) & 1) return;      // the cull: see k_single2
+    ent &= 0x0000ffffffffffffull;
     const double X0 = a.M[0] * xb + a.M[1] * y + a.M[2];
     const double Y0 = a.M[3] * xb + a.M[4] * y + a.M[5];
     const double W0 = a.M[6] * xb + a.M[7] * y + a.M[8];
@@ -161,15 +163,27 @@ __device__ __forceinline__ void single_coords(const WarpArgs& a, const SingleCol
     }
 }
 
+//   * (round 6) whole block ROWS of the canvas go to one XCD each, row r to XCD r mod 8: the hardware hands consecutive workgroup ids to the
+//     8 XCDs round robin, so with a plain 2-D grid the horizontal neighbours of a block -- which read the same 128-byte frame lines and weight
+//     bytes -- ran on seven other XCDs with L2s of their own (FETCH 171 MB per keyframe for 106 MB of reads, profiles/r05_single_band_traffic.txt).
+//     (Contiguous BANDS of rows per XCD fetch as little, 104 MB, but leave the XCDs that hold the canvas's top and bottom -- mostly outside
+//     the frame's footprint -- idle early: 65 us instead of 62, profiles/r06_single_band.md.)
 __global__ __launch_bounds__(256) void k_single2(const uint8_t* __restrict__ src, const uint8_t* __restrict__ w8, WarpArgs a,
-                                                  const uint64_t* __restrict__ table, int tiles_x, int plain)
+                                                  const uint64_t* __restrict__ table, int tiles_x, int plain, int nbx, int nblk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int xb = a.x_off + blockIdx.x * 64;
+    // workgroup id b runs on XCD b & 7 and is the (b >> 3)-th workgroup there: block rows xcd, xcd + 8, xcd + 16, ... left to right
+    const int i = (int)(blockIdx.x >> 3), ri = i / nbx, bx_ = i - ri * nbx, by_ = ri * 8 + (int)(blockIdx.x & 7);
+    if (by_ * nbx >= nblk) return;
+    const int xb = a.x_off + bx_ * 64;
     const int x  = xb + lane;
-    const int yb = a.y_off + blockIdx.y * 32 + wave * 8;
-    const uint64_t ent = table[(yb >> 8) * tiles_x + (x >> 8)];
+    const int yb = a.y_off + by_ * 32 + wave * 8;
+    uint64_t ent = table[(yb >> 8) * tiles_x + (x >> 8)];
     if (!ent) return;
+    // the cull (fusion_map.cpp build_tile_table): bits 48..63 of an entry flag the 64 x 64 cells of the tile in which this keyframe cannot
+    // raise a stored alpha; a block (64 x 32) lies inside one cell
+    if ((ent >> (48 + ((yb >> 6) & 3) * 4 + ((xb >> 6) & 3))) & 1) return;
+    ent &= 0x0000ffffffffffffull;
     const SingleCol col = { a.M[0] * xb, a.M[3] * xb, a.M[6] * xb, a.M[0] * lane, a.M[3] * lane, a.M[6] * lane };
     const int cn = a.src_cn, step = (int)a.sstep;
     const uint32_t hisel = cn == 3 ? 0x06050403u : 0x07060504u;
@@ -252,8 +266,11 @@ void launch_single(hipStream_t s, const uint8_t* src, const uint8_t* w8, const W
     // plain: see FusedWarp::plain (kernels.hip)
     int plain = a.srows <= 32767 && a.scols <= 32767 && !exp_env("PF_FORCE_GENERAL");
     for (int i = 0; i < 9; i++) if (!(std::fabs(a.M[i]) < 0x1p400)) plain = 0;
-    dim3 grid(a.wcols / 64, a.wrows / 32), block(256);
-    hipLaunchKernelGGL(k_single2, grid, block, 0, s, src, w8, a, table, tiles_x, plain);
+    const int nbx = a.wcols / 64, nblk = nbx * (a.wrows / 32);
+    if (nblk <= 0) return;
+    const int nby = a.wrows / 32;
+    dim3 grid((unsigned)(((nby + 7) >> 3) << 3) * (unsigned)nbx), block(256);
+    hipLaunchKernelGGL(k_single2, grid, block, 0, s, src, w8, a, table, tiles_x, plain, nbx, nblk);
 }
 
 }  // namespace pf

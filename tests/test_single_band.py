@@ -129,3 +129,37 @@ def test_single_band_other_kernel_forms(env):
     assert os.path.exists(exp), "build the experiments library first (__graft_entry__.build())"
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{env: "1", "PF_LIB": exp}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "single band ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_single_band_cull_leaves_the_tiles_alone(pf, orc, seed):
+    """Round 6: the cull of the multi-band path serves Map2DCPU semantics too -- a 64 x 64 cell in which a keyframe cannot raise a stored alpha
+    (`if (ele.a < dst.a)`, Map2DCPU.cpp:326-327: 254 wmax <= 254 wlb - 3 with the radial-weight bounds of fusion_map.cpp's cell_out) is left
+    out of the launch.  Overlapping sorties at several scales, yaw and tilt jitters and both weight types, the start flown over again: every
+    tile byte for byte the oracle's (which renders everything), with cells really culled."""
+    wl = workloads()
+    rs = np.random.RandomState(7300 + seed)
+    cam = [640, 480, 500, 500, 320, 240]
+    wt = seed & 1; scale = float(rs.choice([1.0, 1.5, 2.0, 3.0]))
+    yaw = float(rs.choice([3.0, 12.0, 45.0, 180.0])); tilt = float(rs.choice([0.5, 4.0, 10.0]))
+    nfr = int(rs.randint(12, 22))
+    poses = wl.serpentine(cam, float(rs.uniform(60, 140)), nfr, per_row=int(rs.randint(3, 7)), fwd_overlap=float(rs.uniform(0.5, 0.9)),
+                          side_overlap=float(rs.uniform(0.3, 0.8)), seed=seed, yaw_jitter_deg=yaw, tilt_jitter_deg=tilt, max_rows=3)
+    poses = poses + [list(p) for p in poses[:3]]
+    frames = [wl.noise_frame(480, 640, 50 * seed + k) if k % 3 else wl.smooth_frame(480, 640, k) for k in range(len(poses))]
+    g, o = run_pair(pf, orc, cam, poses, frames, pf.TypeCPU if seed & 2 else pf.TypeGPU, n_prepare=6, weight_type=wt, scale=scale)
+    bad = [t for t in o.tiles() if not np.array_equal(g.tile_bgra(*t), o.tile_bgra(*t))]
+    assert bad == [], (seed, bad[:4])
+    assert g.culled_tiles() + g.culled_cells() > 0, "the sortie overlaps: something must have been culled"
+    # ... and with the cull off the same tiles once more (pf_set_cull)
+    if seed < 2:
+        g2 = pf.Map2D.create(pf.TypeCPU, False, weight_type=wt, scale=scale)
+        g2.set_cull(False)
+        assert g2.prepare(wl.IDENTITY_PLANE, cam, poses[:6])
+        for f, p in zip(frames, poses):
+            g2.feed(f, p)
+        g2.sync()
+        assert g2.culled_tiles() + g2.culled_cells() == 0
+        for t in o.tiles():
+            assert np.array_equal(g2.tile_bgra(*t), o.tile_bgra(*t)), t

@@ -2,7 +2,8 @@
 """Map2DCPU (single band) GPU path on the bench workload (dev tool): keyframes/s and the kernel's event time.
 PF_SINGLE_OLD=1 selects the one-pixel-per-thread kernel."""
 import importlib, os, sys, time
-os.environ.setdefault("PF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pi-slam-fusion_amd", "libpifusion_exp.so"))   # the switches below exist in the experiments build only (csrc/env.hpp)
+if os.environ.get("PF_SINGLE_OLD") or os.environ.get("PF_FORCE_GENERAL"):      # these switches exist in the experiments build only (csrc/env.hpp)
+    os.environ.setdefault("PF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pi-slam-fusion_amd", "libpifusion_exp.so"))
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import bench
