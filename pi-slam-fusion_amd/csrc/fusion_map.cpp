@@ -2007,8 +2007,12 @@ bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* 
 
 bool FusionMap::blend_list(const std::vector<std::pair<int, int>>& tiles, uint8_t* bgr)
 {
+    if (single_band_) {          // the Map2DCPU tile is displayable as is (see blend_tile): a tile that does not exist keeps the buffer's bytes
+        for (size_t i = 0; i < tiles.size(); i++) (void)blend_tile(tiles[i].first, tiles[i].second, nullptr, bgr + i * (size_t)kElePixels * kElePixels * 3, nullptr);
+        return init_ok_;
+    }
     std::lock_guard<std::mutex> l(mu_);
-    if (!init_ok_ || !set_device() || single_band_) return false;
+    if (!init_ok_ || !set_device()) return false;
     return blend_batch(tiles, nullptr, nullptr, bgr);
 }
 

@@ -3,8 +3,12 @@
 // over IDAT chunks) when the name ends in .png, binary PPM otherwise.
 #include "../../include/pifusion.h"
 #include "jpeg_decode.hpp"
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <thread>
 #include <vector>
 #include <zlib.h>
 
@@ -24,6 +28,39 @@ static bool png_chunk(FILE* f, const char* tag, const uint8_t* data, uint32_t le
     return std::fwrite(hdr, 1, 8, f) == 8 && (!len || std::fwrite(data, 1, len, f) == len) && std::fwrite(tail, 1, 4, f) == 4;
 }
 
+// The zlib stream of the IDAT chunks is made band by band (kBandRows rows each) on a few threads: every band is a raw deflate stream of its
+// own (no history before the band, ended on a byte boundary by Z_SYNC_FLUSH, the last one by Z_FINISH), and raw deflate streams laid end
+// to end behind one zlib header are one valid zlib stream when the Adler-32 of all the bytes follows (adler32_combine) -- what pigz does with
+// independent blocks.  The bands are fixed, so the file's bytes do not depend on the number of threads.  A 12 800 x 15 104 mosaic (580 MB)
+// took 4-6 s on one thread (deflate level 1); the reference hands the same pixels to cv::imwrite (MultiBandMap2DCPU.cpp:841).
+constexpr int kBandRows = 256;
+
+static bool deflate_band(const uint8_t* bgr, int cols, int y0, int y1, bool last, std::vector<uint8_t>& out, uLong* adler)
+{
+    z_stream zs{};
+    if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    const size_t line_bytes = (size_t)cols * 3 + 1;
+    std::vector<uint8_t> line(line_bytes);
+    out.resize(deflateBound(&zs, (uLong)(line_bytes * (size_t)(y1 - y0))) + 64);
+    zs.next_out = out.data(); zs.avail_out = (uInt)std::min<size_t>(out.size(), 0xffffffffu);
+    uLong ad = adler32(0L, Z_NULL, 0);
+    bool ok = true;
+    for (int y = y0; y < y1 && ok; y++) {
+        line[0] = 0;                                               // filter type 0
+        const uint8_t* s = bgr + (size_t)y * cols * 3;
+        for (int x = 0; x < cols; x++) { line[1 + 3 * x] = s[3 * x + 2]; line[2 + 3 * x] = s[3 * x + 1]; line[3 + 3 * x] = s[3 * x]; }
+        ad = adler32(ad, line.data(), (uInt)line_bytes);
+        zs.next_in = line.data(); zs.avail_in = (uInt)line_bytes;
+        const int flush = y == y1 - 1 ? (last ? Z_FINISH : Z_SYNC_FLUSH) : Z_NO_FLUSH;
+        const int r = deflate(&zs, flush);
+        ok = r != Z_STREAM_ERROR && zs.avail_in == 0 && (flush != Z_FINISH || r == Z_STREAM_END);
+    }
+    out.resize(ok ? (size_t)zs.total_out : 0);
+    deflateEnd(&zs);
+    *adler = ad;
+    return ok;
+}
+
 static bool write_png(FILE* f, const uint8_t* bgr, int rows, int cols)
 {
     static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n' };
@@ -32,25 +69,46 @@ static bool write_png(FILE* f, const uint8_t* bgr, int rows, int cols)
     put_be32(ihdr, (uint32_t)cols); put_be32(ihdr + 4, (uint32_t)rows);
     ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     if (!png_chunk(f, "IHDR", ihdr, 13)) return false;
-    z_stream zs{};
-    if (deflateInit(&zs, 1) != Z_OK) return false;
-    std::vector<uint8_t> line((size_t)cols * 3 + 1), out(1 << 20);
-    bool ok = true;
-    for (int y = 0; y < rows && ok; y++) {
-        line[0] = 0;
-        const uint8_t* s = bgr + (size_t)y * cols * 3;
-        for (int x = 0; x < cols; x++) { line[1 + 3 * x] = s[3 * x + 2]; line[2 + 3 * x] = s[3 * x + 1]; line[3 + 3 * x] = s[3 * x]; }
-        zs.next_in = line.data(); zs.avail_in = (uInt)line.size();
-        const int flush = (y == rows - 1) ? Z_FINISH : Z_NO_FLUSH;
-        do {
-            zs.next_out = out.data(); zs.avail_out = (uInt)out.size();
-            const int r = deflate(&zs, flush);
-            if (r == Z_STREAM_ERROR) { ok = false; break; }
-            const uint32_t have = (uint32_t)(out.size() - zs.avail_out);
-            if (have && !png_chunk(f, "IDAT", out.data(), have)) { ok = false; break; }
-        } while (zs.avail_out == 0);
+    const int nbands = (rows + kBandRows - 1) / kBandRows;
+    std::vector<std::vector<uint8_t>> comp(nbands);
+    std::vector<uLong> adl(nbands, 1);
+    std::vector<char> good(nbands, 0);
+    std::atomic<int> next{ 0 };
+    auto work = [&] {
+        for (int b = next.fetch_add(1); b < nbands; b = next.fetch_add(1)) {
+            const int y0 = b * kBandRows, y1 = std::min(rows, y0 + kBandRows);
+            try { good[b] = deflate_band(bgr, cols, y0, y1, b == nbands - 1, comp[b], &adl[b]) ? 1 : 0; }
+            catch (const std::bad_alloc&) { good[b] = 0; }
+        }
+    };
+    const unsigned hc = std::thread::hardware_concurrency();
+    const int nthreads = std::max(1, std::min({ nbands, 8, (int)(hc / 2) }));
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    // the stream: zlib header (deflate, 32 K window, fastest), the bands, the Adler-32 of everything -- cut into IDAT chunks of at most 1 MB
+    std::vector<uint8_t> buf; buf.reserve((1 << 20) + 16);
+    auto flush_chunk = [&]() { const bool ok = buf.empty() || png_chunk(f, "IDAT", buf.data(), (uint32_t)buf.size()); buf.clear(); return ok; };
+    auto put = [&](const uint8_t* p, size_t n) {
+        while (n) {
+            const size_t room = ((size_t)1 << 20) - buf.size(), k = std::min(room, n);
+            buf.insert(buf.end(), p, p + k); p += k; n -= k;
+            if (buf.size() == ((size_t)1 << 20) && !flush_chunk()) return false;
+        }
+        return true;
+    };
+    const uint8_t zhdr[2] = { 0x78, 0x01 };
+    bool ok = put(zhdr, 2);
+    uLong ad = 1;
+    for (int b = 0; b < nbands && ok; b++) {
+        ok = good[b] && put(comp[b].data(), comp[b].size());
+        const int y0 = b * kBandRows, y1 = std::min(rows, y0 + kBandRows);
+        ad = b == 0 ? adl[0] : adler32_combine(ad, adl[b], (z_off_t)((size_t)(y1 - y0) * ((size_t)cols * 3 + 1)));
+        std::vector<uint8_t>().swap(comp[b]);
     }
-    deflateEnd(&zs);
+    uint8_t tail[4]; put_be32(tail, (uint32_t)ad);
+    ok = ok && put(tail, 4) && flush_chunk();
     return ok && png_chunk(f, "IEND", nullptr, 0);
 }
 

@@ -257,7 +257,7 @@ static void check_datatrans()
 static void check_writer(const std::string& work)
 {
     for (int it = 0; it < 40; it++) {
-        const int r = 1 + (int)rnd_below(70), c = 1 + (int)rnd_below(90);
+        const int r = it < 36 ? 1 + (int)rnd_below(70) : 250 + (int)rnd_below(600), c = 1 + (int)rnd_below(90);      // the last few: several 256-row bands (the writer's threads)
         std::vector<uint8_t> px((size_t)r * c * 3);
         for (auto& v : px) v = (uint8_t)rnd();
         for (const char* ext : { ".png", ".ppm" }) {

@@ -110,6 +110,17 @@ int main(int argc, char** argv)
         for (auto& x : pt) x.join();
         for (int a = 0; a < n; a++) for (int b = 0; b < n; b++) if (plan[a].send_bytes[b] != plan[b].recv_bytes[a]) { std::printf("plans disagree\n"); bad++; }
     }
+    // 4. the PNG writer compresses bands of 256 rows on threads of its own: two writers at once, each with several bands
+    {
+        std::vector<uint8_t> px((size_t)900 * 70 * 3);
+        for (size_t i = 0; i < px.size(); i++) px[i] = (uint8_t)(i * 2654435761u >> 13);
+        const std::string dir = argc > 3 ? argv[3] : "/tmp";
+        std::thread a([&] { if (!pf_write_image((dir + "/tsan_a.png").c_str(), px.data(), 900, 70)) bad++; });
+        std::thread b([&] { if (!pf_write_image((dir + "/tsan_b.png").c_str(), px.data(), 700, 90)) bad++; });
+        a.join(); b.join();
+        std::vector<uint8_t> back((size_t)900 * 70 * 3);
+        if (!pf_read_image((dir + "/tsan_a.png").c_str(), back.data(), 900, 70) || back != px) { std::printf("PNG written on threads reads back differently\n"); bad++; }
+    }
     std::printf("files %zu threads %d violations %d\n", files.size(), T, bad);
     return bad ? 1 : 0;
 }

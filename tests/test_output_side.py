@@ -71,6 +71,16 @@ def test_write_image_large_stream_splits_into_idat_chunks(pf, tmp_path):
     assert pf.write_image(png, bgr)
     assert open(png, "rb").read().count(b"IDAT") >= 2
     assert np.array_equal(decode_png(png), bgr[:, :, ::-1])
+    # the zlib stream is made in bands of 256 rows on several threads (raw deflate streams end to end behind one header, Adler-32 combined):
+    # one stream to every reader, whatever the band count -- exactly one band, one row more, several, compressible and not
+    from PIL import Image
+    for rows, cols, smooth in ((256, 40, False), (257, 33, True), (512, 17, False), (1100, 90, True), (1, 1, False)):
+        a = np.random.RandomState(rows).randint(0, 256, (rows, cols, 3)).astype(np.uint8)
+        if smooth:
+            a = (np.add.outer(np.arange(rows), np.arange(cols))[:, :, None] // 3 + np.arange(3)).astype(np.uint8)
+        p = str(tmp_path / ("b%d.png" % rows))
+        assert pf.write_image(p, a)
+        assert np.array_equal(decode_png(p), a[:, :, ::-1]) and np.array_equal(np.asarray(Image.open(p).convert("RGB")), a[:, :, ::-1]), rows
 
 
 def test_write_image_fails_like_imwrite(pf, tmp_path):

@@ -134,9 +134,9 @@ def test_address_and_undefined_behaviour_sanitizers(san, tmp_path):
     assert total >= 10000
 
 
-def test_thread_sanitizer(san):
+def test_thread_sanitizer(san, tmp_path):
     out, corpus, _ = san
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
-    r = subprocess.run([os.path.join(out, "san_threads"), corpus, "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    r = subprocess.run([os.path.join(out, "san_threads"), corpus, "8", str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     text = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in text and "violations 0" in text, text[-4000:]

@@ -64,6 +64,8 @@ def test_single_band_against_oracle(pf, orc, typ, weight_type):
     assert g.num_levels == 1
     t = o.tiles()[len(o.tiles()) // 2]
     assert np.array_equal(g.blend_tile(*t), o.tile_bgra(*t)[:, :, :3])
+    got = g.blend_tiles([t, (10 ** 6, 0), o.tiles()[0]])                 # the list form: a tile that does not exist keeps the buffer's bytes
+    assert np.array_equal(got[0], o.tile_bgra(*t)[:, :, :3]) and (got[1] == 0).all() and np.array_equal(got[2], o.tile_bgra(*o.tiles()[0])[:, :, :3])
     changed, imgs = g.blend_changed()
     assert sorted(changed) == sorted(o.tiles()) and g.blend_changed()[0] == []
     img, org = g.save_to_memory()

@@ -58,3 +58,10 @@ if hasattr(pf, "host_array"):
             t0 = time.perf_counter(); m.save_to_memory(alloc=al); best = min(best, time.perf_counter() - t0)
         print("save_to_memory: into a %s buffer: best %.1f ms = %.1f GB/s of BGR8" % (name, best * 1e3, img[0].nbytes / best / 1e9))
     dump()
+import tempfile
+with tempfile.TemporaryDirectory() as d:
+    for ext in ("png", "ppm"):
+        p = os.path.join(d, "mosaic." + ext)
+        t0 = time.perf_counter(); ok = m.save(p); t1 = time.perf_counter()
+        print("save(%s): %s in %.2f s, file %.0f MB (collapse + D2H + encode on the host: PNG deflate level 1 in 256-row bands on up to 8 threads)" %
+              (ext, "ok" if ok else "FAILED", t1 - t0, os.path.getsize(p) / 1e6))
