@@ -103,6 +103,20 @@ __device__ __forceinline__ Reg level_region(int level, int Y0, int X0, int rows0
 // idx / w for 0 <= idx < 4096, 1 <= w <= 128, rcp = 1.f / w: (idx + 0.5) / w is at least 1 / 256 away from an integer, the float error is below 2^-10
 __device__ __forceinline__ int div_small(int idx, float rcp) { return (int)(((float)idx + 0.5f) * rcp); }
 
+// three components of a pixel.  int16 pixels (6 bytes, 2-byte aligned) of a TILE SLOT are read as one 8-byte load: the two bytes behind a
+// pixel are the next pixel's or the level's alignment padding inside the slot (levels are 256-byte aligned, the weights follow the last one).
+// Packed halo strips keep three 2-byte loads: their last pixel may be the last bytes of the exchange buffer.
+template <bool F32, bool SLOT>
+__device__ __forceinline__ void load_px(const PF_GLOBAL typename Px<F32>::T* s, typename Px<F32>::WT out[3])
+{
+    using WT = typename Px<F32>::WT;
+    if constexpr (!F32 && SLOT) {
+        typedef uint32_t u2u __attribute__((ext_vector_type(2), aligned(1)));
+        const u2u v = *(const PF_GLOBAL u2u*)s;
+        out[0] = (int)(short)(v.x & 0xffffu); out[1] = (int)v.x >> 16; out[2] = (int)(short)(v.y & 0xffffu);
+    } else { out[0] = (WT)s[0]; out[1] = (WT)s[1]; out[2] = (WT)s[2]; }
+}
+
 __device__ __forceinline__ void strip_dims_d(int nlev, int level, int dx, int dy, int& w, int& h)
 {
     const int ts = kElePixels >> level, b = 1 << (nlev - 1 - level);
@@ -113,7 +127,7 @@ __device__ __forceinline__ void strip_dims_d(int nlev, int level, int dx, int dy
 template <bool F32>
 __device__ __forceinline__ void fetch_blend(const BlendJob& job, int nlev, int level, int lap_off, int py, int px, typename Px<F32>::WT out[3])
 {
-    using T = typename Px<F32>::T; using WT = typename Px<F32>::WT;
+    using T = typename Px<F32>::T;
     const int ts = kElePixels >> level, b = job.border ? 1 << (nlev - 1 - level) : 0;
     int rx = 1, sx = px - b, ry = 1, sy = py - b;
     if (sx < 0) { rx = 0; sx += ts; } else if (sx >= ts) { rx = 2; sx -= ts; }
@@ -122,6 +136,8 @@ __device__ __forceinline__ void fetch_blend(const BlendJob& job, int nlev, int l
     const PF_GLOBAL T* s;
     if (!((job.strip_mask >> j) & 1)) {
         s = (const PF_GLOBAL T*)((const PF_GLOBAL char*)job.src[j] + lap_off) + (sy * ts + sx) * 3;
+        load_px<F32, true>(s, out);
+        return;
     } else {                                              // packed strips: levels concatenated, each h x w row-major from the strip's corner
         const int dx = rx - 1, dy = ry - 1;
         int off = 0;
@@ -130,7 +146,7 @@ __device__ __forceinline__ void fetch_blend(const BlendJob& job, int nlev, int l
         const int lx = rx == 0 ? sx - (ts - b) : sx, ly = ry == 0 ? sy - (ts - b) : sy;
         s = (const PF_GLOBAL T*)job.src[j] + (off + ly * w + lx) * 3;
     }
-    out[0] = (WT)s[0]; out[1] = (WT)s[1]; out[2] = (WT)s[2];
+    load_px<F32, false>(s, out);
 }
 
 // ... of the pasted mosaic (save, .cpp:806-834): absent tiles are zero
@@ -142,7 +158,7 @@ __device__ __forceinline__ void fetch_mosaic(const uint64_t* __restrict__ table,
     const uint64_t ent = table[(py >> sh) * wx + (px >> sh)];
     if (!ent) { out[0] = out[1] = out[2] = (WT)0; return; }
     const PF_GLOBAL T* s = (const PF_GLOBAL T*)((const PF_GLOBAL char*)ent + lap_off) + ((py & (ts - 1)) * ts + (px & (ts - 1))) * 3;
-    out[0] = (WT)s[0]; out[1] = (WT)s[1]; out[2] = (WT)s[2];
+    load_px<F32, true>(s, out);
 }
 
 // 4 consecutive level-0 pixels of a row (12 components): loads and stores by the widest aligned pieces
