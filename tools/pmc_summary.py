@@ -61,7 +61,7 @@ def stats(d):
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|")
     for r in rows:
-        n = re.sub(r"\(.*", "", r["Name"])[:70]
+        n = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", ""))[:70]
         print("| %s | %s | %.3f | %.2f | %.2f | %.2f | %s |" % (n, r["Calls"], float(r["TotalDurationNs"]) / 1e6,
               float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
     full_launches(d)
