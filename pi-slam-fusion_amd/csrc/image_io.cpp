@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -31,33 +34,37 @@ static bool png_chunk(FILE* f, const char* tag, const uint8_t* data, uint32_t le
 // The zlib stream of the IDAT chunks is made band by band (kBandRows rows each) on a few threads: every band is a raw deflate stream of its
 // own (no history before the band, ended on a byte boundary by Z_SYNC_FLUSH, the last one by Z_FINISH), and raw deflate streams laid end
 // to end behind one zlib header are one valid zlib stream when the Adler-32 of all the bytes follows (adler32_combine) -- what pigz does with
-// independent blocks.  The bands are fixed, so the file's bytes do not depend on the number of threads.  A 12 800 x 15 104 mosaic (580 MB)
-// took 4-6 s on one thread (deflate level 1); the reference hands the same pixels to cv::imwrite (MultiBandMap2DCPU.cpp:841).
+// independent blocks.  The bands are fixed, so the file's bytes do not depend on the number of threads.  The reference hands the same
+// pixels to cv::imwrite (MultiBandMap2DCPU.cpp:841), one thread.
 constexpr int kBandRows = 256;
 
-static bool deflate_band(const uint8_t* bgr, int cols, int y0, int y1, bool last, std::vector<uint8_t>& out, uLong* adler)
+struct Band { std::unique_ptr<uint8_t[]> data; size_t size = 0; uLong adler = 1; int state = 0; };      // state: 0 pending, 1 done, -1 failed
+
+static bool deflate_band(const uint8_t* bgr, int cols, int y0, int y1, bool last, Band& out)
 {
     z_stream zs{};
     if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    const size_t line_bytes = (size_t)cols * 3 + 1;
-    std::vector<uint8_t> line(line_bytes);
-    out.resize(deflateBound(&zs, (uLong)(line_bytes * (size_t)(y1 - y0))) + 64);
-    zs.next_out = out.data(); zs.avail_out = (uInt)std::min<size_t>(out.size(), 0xffffffffu);
-    uLong ad = adler32(0L, Z_NULL, 0);
-    bool ok = true;
-    for (int y = y0; y < y1 && ok; y++) {
-        line[0] = 0;                                               // filter type 0
+    const size_t line_bytes = (size_t)cols * 3 + 1, raw = line_bytes * (size_t)(y1 - y0);
+    const size_t cap = deflateBound(&zs, (uLong)raw) + 64;
+    if (cap > 0xffffffffu) { deflateEnd(&zs); return false; }
+    out.data.reset(new (std::nothrow) uint8_t[cap]);                 // (not value-initialised: 30 MB a band)
+    std::vector<uint8_t> lines;
+    try { lines.resize(raw); } catch (const std::bad_alloc&) { out.data.reset(); }
+    if (!out.data) { deflateEnd(&zs); return false; }
+    // the band's filtered rows (filter type 0, BGR -> RGB), then ONE deflate call
+    for (int y = y0; y < y1; y++) {
+        uint8_t* line = lines.data() + (size_t)(y - y0) * line_bytes;
+        line[0] = 0;
         const uint8_t* s = bgr + (size_t)y * cols * 3;
         for (int x = 0; x < cols; x++) { line[1 + 3 * x] = s[3 * x + 2]; line[2 + 3 * x] = s[3 * x + 1]; line[3 + 3 * x] = s[3 * x]; }
-        ad = adler32(ad, line.data(), (uInt)line_bytes);
-        zs.next_in = line.data(); zs.avail_in = (uInt)line_bytes;
-        const int flush = y == y1 - 1 ? (last ? Z_FINISH : Z_SYNC_FLUSH) : Z_NO_FLUSH;
-        const int r = deflate(&zs, flush);
-        ok = r != Z_STREAM_ERROR && zs.avail_in == 0 && (flush != Z_FINISH || r == Z_STREAM_END);
     }
-    out.resize(ok ? (size_t)zs.total_out : 0);
+    out.adler = adler32(adler32(0L, Z_NULL, 0), lines.data(), (uInt)raw);
+    zs.next_in = lines.data(); zs.avail_in = (uInt)raw;
+    zs.next_out = out.data.get(); zs.avail_out = (uInt)cap;
+    const int r = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+    const bool ok = r != Z_STREAM_ERROR && zs.avail_in == 0 && zs.avail_out > 0 && (!last || r == Z_STREAM_END);
+    out.size = ok ? (size_t)zs.total_out : 0;
     deflateEnd(&zs);
-    *adler = ad;
     return ok;
 }
 
@@ -70,23 +77,22 @@ static bool write_png(FILE* f, const uint8_t* bgr, int rows, int cols)
     ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     if (!png_chunk(f, "IHDR", ihdr, 13)) return false;
     const int nbands = (rows + kBandRows - 1) / kBandRows;
-    std::vector<std::vector<uint8_t>> comp(nbands);
-    std::vector<uLong> adl(nbands, 1);
-    std::vector<char> good(nbands, 0);
+    std::vector<Band> band(nbands);
+    std::mutex mu; std::condition_variable cv;
     std::atomic<int> next{ 0 };
     auto work = [&] {
         for (int b = next.fetch_add(1); b < nbands; b = next.fetch_add(1)) {
             const int y0 = b * kBandRows, y1 = std::min(rows, y0 + kBandRows);
-            try { good[b] = deflate_band(bgr, cols, y0, y1, b == nbands - 1, comp[b], &adl[b]) ? 1 : 0; }
-            catch (const std::bad_alloc&) { good[b] = 0; }
+            const bool ok = deflate_band(bgr, cols, y0, y1, b == nbands - 1, band[b]);
+            { std::lock_guard<std::mutex> l(mu); band[b].state = ok ? 1 : -1; }
+            cv.notify_all();
         }
     };
+    // the bands are compressed by up to eight threads while this one writes them out, in order, as they become ready
     const unsigned hc = std::thread::hardware_concurrency();
-    const int nthreads = std::max(1, std::min({ nbands, 8, (int)(hc / 2) }));
+    const int nthreads = std::max(1, std::min({ nbands, 8, (int)hc }));
     std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    for (int t = 0; t < nthreads; t++) th.emplace_back(work);
     // the stream: zlib header (deflate, 32 K window, fastest), the bands, the Adler-32 of everything -- cut into IDAT chunks of at most 1 MB
     std::vector<uint8_t> buf; buf.reserve((1 << 20) + 16);
     auto flush_chunk = [&]() { const bool ok = buf.empty() || png_chunk(f, "IDAT", buf.data(), (uint32_t)buf.size()); buf.clear(); return ok; };
@@ -101,12 +107,14 @@ static bool write_png(FILE* f, const uint8_t* bgr, int rows, int cols)
     const uint8_t zhdr[2] = { 0x78, 0x01 };
     bool ok = put(zhdr, 2);
     uLong ad = 1;
-    for (int b = 0; b < nbands && ok; b++) {
-        ok = good[b] && put(comp[b].data(), comp[b].size());
+    for (int b = 0; b < nbands; b++) {
+        { std::unique_lock<std::mutex> l(mu); cv.wait(l, [&] { return band[b].state != 0; }); }
+        ok = ok && band[b].state == 1 && put(band[b].data.get(), band[b].size);
         const int y0 = b * kBandRows, y1 = std::min(rows, y0 + kBandRows);
-        ad = b == 0 ? adl[0] : adler32_combine(ad, adl[b], (z_off_t)((size_t)(y1 - y0) * ((size_t)cols * 3 + 1)));
-        std::vector<uint8_t>().swap(comp[b]);
+        ad = b == 0 ? band[0].adler : adler32_combine(ad, band[b].adler, (z_off_t)((size_t)(y1 - y0) * ((size_t)cols * 3 + 1)));
+        band[b].data.reset();
     }
+    for (auto& t : th) t.join();
     uint8_t tail[4]; put_be32(tail, (uint32_t)ad);
     ok = ok && put(tail, 4) && flush_chunk();
     return ok && png_chunk(f, "IEND", nullptr, 0);
