@@ -176,7 +176,8 @@ int pf_blend_tiles(pf_map* m, const int* xy, int n, uint8_t* bgr)
 void* pf_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    // portable: page-locked for every device of the process (a node's maps live on different GPUs)
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return p;
 }
 void pf_host_free(void* p) { if (p) (void)hipHostFree(p); }

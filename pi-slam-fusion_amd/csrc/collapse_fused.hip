@@ -257,21 +257,33 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
 
     // ---- 1. Laplacian regions of levels 1..L -> LDS; the loads of a thread are issued in batches before their LDS stores
     if (L >= 1 && !(PF_CF_ABLATE & 1)) {
-        // level 1 (three in five of the pixels): its region is workgroup-uniform, the index arithmetic scalar
-        constexpr int kIts1 = (region_px(1) + kCT - 1) / kCT;                 // 5
-        const int n1 = r1.h * r1.w, lap1 = (int)lay.lap_off[1];
-        const float rcp1 = 1.f / (float)r1.w;
-        WT v[kIts1][3];
-#pragma unroll
-        for (int it = 0; it < kIts1; it++) {
-            const int idx = rt + it * kCT;
-            v[it][0] = v[it][1] = v[it][2] = (WT)0;
-            if (idx < n1) {
-                const int ry = div_small(idx, rcp1), rx = idx - ry * r1.w;
-                if constexpr (MOSAIC) fetch_mosaic<F32>(table, wx, 1, lap1, r1.y0 + ry, r1.x0 + rx, v[it]);
-                else fetch_blend<F32>(sh.job, lay.nlev, 1, lap1, r1.y0 + ry, r1.x0 + rx, v[it]);
-            }
+        // level 1 (three in five of the pixels).  Its INTERIOR -- the (kBW / 2) x (kBH / 2) pixels under the block itself -- lies in the block's own
+        // tile: a thread takes four pixels of a row with the widest aligned loads (48 / 24 bytes), exactly one such task per thread.  The RING
+        // around it (one pixel where the level's image goes on: up to 2 (66 + 16) pixels, possibly another tile's or a halo strip's) goes pixel by
+        // pixel.  (Round 6, first form: the whole region pixel by pixel, five fetches a thread -- 225 vector instructions per wave more.)
+        static_assert((kBW / 2 / 4) * (kBH / 2) == kCT, "one interior task per thread");
+        const int lap1 = (int)lay.lap_off[1];
+        const int iy0 = Y0 >> 1, ix0 = X0 >> 1;                                 // the interior's first row / column in the level-1 image
+        Row4<F32> in4;
+        {
+            const int r = rt / (kBW / 8), cq = rt - r * (kBW / 8);
+            in4.load((const PF_GLOBAL T*)(self + lap1) + (((ly0 >> 1) + r) * (kElePixels >> 1) + (lx0 >> 1) + 4 * cq) * 3);
         }
+        const int ta = iy0 - r1.y0, tb = r1.y0 + r1.h - (iy0 + kBH / 2), la = ix0 - r1.x0, lb = r1.x0 + r1.w - (ix0 + kBW / 2);      // ring: rows above / below, columns left / right (0 or 1 each)
+        const int n_top = ta * r1.w, n_bot = tb * r1.w, n_left = la * (kBH / 2), n_ring = n_top + n_bot + n_left + lb * (kBH / 2);
+        WT v[3]; int ring_idx = -1;
+        v[0] = v[1] = v[2] = (WT)0;
+        if (rt < n_ring) {
+            int ry, rx;
+            if (rt < n_top) { ry = 0; rx = rt; }
+            else if (rt < n_top + n_bot) { ry = r1.h - 1; rx = rt - n_top; }
+            else if (rt < n_top + n_bot + n_left) { ry = ta + (rt - n_top - n_bot); rx = 0; }
+            else { ry = ta + (rt - n_top - n_bot - n_left); rx = r1.w - 1; }
+            ring_idx = ry * r1.w + rx;
+            if constexpr (MOSAIC) fetch_mosaic<F32>(table, wx, 1, lap1, r1.y0 + ry, r1.x0 + rx, v);
+            else fetch_blend<F32>(sh.job, lay.nlev, 1, lap1, r1.y0 + ry, r1.x0 + rx, v);
+        }
+        const int n1 = r1.h * r1.w;
         // levels 2..L: the flat list dealt over the threads
         constexpr int kIts2 = (region_px_total(2) + kCT - 1) / kCT;           // 3
         WT u[kIts2][3];
@@ -289,11 +301,13 @@ __global__ __launch_bounds__(kCT, kCFWaves) void k_collapse_fused(TileLayout lay
                 else fetch_blend<F32>(sh.job, lay.nlev, lv, r.lap_off, r.y0 + ry, r.x0 + rx, u[it]);
             }
         }
+        {
+            const int r = rt / (kBW / 8), cq = rt - r * (kBW / 8);
+            WT* d = lds + ((ta + r) * r1.w + la + 4 * cq) * 3;
 #pragma unroll
-        for (int it = 0; it < kIts1; it++) {
-            const int idx = rt + it * kCT;
-            if (idx < n1) { lds[idx * 3] = v[it][0]; lds[idx * 3 + 1] = v[it][1]; lds[idx * 3 + 2] = v[it][2]; }
+            for (int e = 0; e < 12; e++) d[e] = in4.in(e);
         }
+        if (ring_idx >= 0) { lds[ring_idx * 3] = v[0]; lds[ring_idx * 3 + 1] = v[1]; lds[ring_idx * 3 + 2] = v[2]; }
 #pragma unroll
         for (int it = 0; it < kIts2; it++) {
             const int idx = n1 + rt + it * kCT;

@@ -1770,13 +1770,15 @@ static bool is_pinned_host(const void* p)
 
 bool FusionMap::out_ring_init()
 {
-    if (out_pin_[0]) return true;
+    if (out_ring_ok_) return true;
+    // (a call that failed half way is finished by the next one: every piece is made once)
     for (int i = 0; i < 2; i++) {
-        HIP_OK(hipHostMalloc((void**)&out_pin_[i], kOutSlot, hipHostMallocDefault));
-        HIP_OK(hipEventCreateWithFlags(&out_copied_[i], hipEventDisableTiming));
+        if (!out_pin_[i]) HIP_OK(hipHostMalloc((void**)&out_pin_[i], kOutSlot, hipHostMallocDefault));
+        if (!out_copied_[i]) HIP_OK(hipEventCreateWithFlags(&out_copied_[i], hipEventDisableTiming));
     }
-    HIP_OK(hipEventCreateWithFlags(&out_ready_, hipEventDisableTiming));
-    HIP_OK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    if (!out_ready_) HIP_OK(hipEventCreateWithFlags(&out_ready_, hipEventDisableTiming));
+    if (!copy_stream_) HIP_OK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+    out_ring_ok_ = true;
     const unsigned hc = std::thread::hardware_concurrency();
     out_threads_ = std::getenv("PF_COPY_THREADS") ? std::atoi(std::getenv("PF_COPY_THREADS")) : (int)std::min(8u, std::max(1u, hc / 2));
     return true;

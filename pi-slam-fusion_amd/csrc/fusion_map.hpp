@@ -326,6 +326,7 @@ private:
     hipEvent_t  out_copied_[2]{}, out_ready_ = nullptr;
     hipStream_t copy_stream_ = nullptr;
     int         out_threads_ = 1;
+    bool        out_ring_ok_ = false;
     bool out_ring_init();
     bool download(const std::vector<OutPiece>& pieces);
 #if PF_EXPERIMENTS
