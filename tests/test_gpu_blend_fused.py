@@ -117,3 +117,35 @@ def test_fused_kernel_equals_per_level_kernels():
         outs.append([l for l in r.stdout.decode().splitlines() if l.startswith("DIGEST")])
     assert len(outs[0]) == 4 and outs[0] == outs[1], outs
     assert all(int(l.split()[3]) > 60 for l in outs[0]), outs[0]
+
+
+def test_blend_tiles_more_than_one_launch(pf):
+    """pf_blend_tiles cuts its list into launches of 4096 tiles (the result buffers in HBM are bounded) and its results into 32 MB pieces for the
+    staging ring: a mosaic of more than 4096 tiles (640 x 480 keyframes at Map2D.Scale = 8: 300 tiles each, sixteen of them side by side)
+    blended in one call equals the tiles blended one at a time -- across the launch boundary, at the list's ends, for a repeated and a missing tile."""
+    wl = workloads()
+    cam = [640, 480, 500, 500, 320, 240]
+    # footprint on the ground at 100 m: 128 x 96 m; keyframes 120 / 90 m apart: a little overlap, 4 x 4 of them
+    poses = [[120.0 * (k % 4), 90.0 * (k // 4), -100.0, 0, 0, 0, 1] for k in range(16)]
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, scale=8.0, band_number=3)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        assert g.feed(wl.smooth_frame(480, 640, k) ^ (wl.noise_frame(480, 640, k) & 7), p)
+    g.sync()
+    tiles = sorted(g.tiles())
+    assert len(tiles) > 4096 + 200, len(tiles)
+    ask = tiles + [tiles[5], (10 ** 6, 3), tiles[-1]]
+    out = np.full((len(ask), 256, 256, 3), 99, np.uint8)
+    assert g.blend_tiles(ask, out=out) is not None
+    rng = np.random.RandomState(5)
+    probe = sorted(set([0, 1, 4094, 4095, 4096, 4097, len(tiles) - 1] + [int(i) for i in rng.randint(0, len(tiles), 30)]))
+    for i in probe:
+        assert np.array_equal(out[i], g.blend_tile(*tiles[i])), (i, tiles[i])
+    assert np.array_equal(out[len(tiles)], out[5]) and (out[len(tiles) + 1] == 99).all() and np.array_equal(out[len(tiles) + 2], out[len(tiles) - 1])
+    # the same through the draw() form with a cap below the tile count, twice: every tile exactly once
+    xy1, im1 = g.blend_changed(cap=4200)
+    xy2, im2 = g.blend_changed(cap=4200)
+    assert len(xy1) == 4200 and len(xy1) + len(xy2) == len(tiles) and sorted(xy1 + xy2) == tiles
+    for j in (0, 4095, 4096, 4199):
+        assert np.array_equal(im1[j], out[tiles.index(xy1[j])])
+    g.close()
