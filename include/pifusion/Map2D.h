@@ -98,7 +98,7 @@ public:
         pf_map* h = pf_create(type, thread ? 1 : 0, opt);
         return h ? std::shared_ptr<Map2D>(new Map2D(h)) : std::shared_ptr<Map2D>();
     }
-    ~Map2D() { pf_destroy(h_); }
+    ~Map2D() { pf_host_free(tex_); pf_destroy(h_); }
     Map2D(const Map2D&) = delete;
     Map2D& operator=(const Map2D&) = delete;
 
@@ -135,10 +135,19 @@ public:
         const int cap = pf_tile_count(h_);
         if (cap <= 0) return;
         std::vector<int> xy(2 * (size_t)cap);
-        std::vector<unsigned char> px((size_t)cap * ELE_PIXELS * ELE_PIXELS * 3);
-        const int n = pf_blend_changed(h_, xy.data(), px.data(), cap);
+        // the tiles come back in ONE launch and one PCIe transfer into a page-locked buffer that this object keeps between draws
+        // (pf_host_alloc: filled straight from HBM; the textures updateTexture hands to GL, .cpp:159-176)
+        const size_t need = (size_t)cap * ELE_PIXELS * ELE_PIXELS * 3;
+        if (tex_cap_ < need) {
+            pf_host_free(tex_); tex_cap_ = 0;
+            tex_ = (unsigned char*)pf_host_alloc(need + need / 4);
+            if (!tex_) return;
+            tex_cap_ = need + need / 4;
+        }
+        unsigned char* px = tex_;
+        const int n = pf_blend_changed(h_, xy.data(), px, cap);
         for (int i = 0; i < n; i++) {
-            if (sink) sink(xy[2 * i], xy[2 * i + 1], &px[(size_t)i * ELE_PIXELS * ELE_PIXELS * 3]);
+            if (sink) sink(xy[2 * i], xy[2 * i + 1], px + (size_t)i * ELE_PIXELS * ELE_PIXELS * 3);
             char cmd[256];
             if (fuse2google_ && announce && pf_map_update_command(h_, xy[2 * i], xy[2 * i + 1], gps_origin_, cmd, (int)sizeof cmd) > 0) announce(cmd);
         }
@@ -167,6 +176,7 @@ public:
 private:
     explicit Map2D(pf_map* h) : h_(h) {}
     pf_map* h_;
+    unsigned char* tex_ = nullptr; size_t tex_cap_ = 0;      // draw()'s page-locked tile buffer
     bool fuse2google_ = false;
     double gps_origin_[3] = { 0, 0, 0 };
 };
