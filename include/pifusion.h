@@ -57,6 +57,14 @@ typedef struct pf_options {
                                 per level; 2: as 3 in the 4-stage 64x16-block shape;
                                 0: one kernel per reference op (warp / pyrDown /
                                 Laplacian+select)                                    */
+    int    lookahead;        /* keyframes that wait, fed but not rendered, so that the cull can leave a keyframe out of the cells
+                                in which one of the NEXT `lookahead` keyframes is bound to overwrite it (default 4; 0: every
+                                keyframe is rendered inside its own feed call).  The select keeps the largest weight, the newest
+                                keyframe among equals, whatever the order, and every call that reads tiles, flags or counters
+                                (pf_sync, blend, save, tile access, statistics) renders what waits first: what a caller can observe
+                                is the map after the keyframes fed so far, exactly as without it.  Unsharded multi-band maps
+                                with fused = 1; elsewhere the value is ignored.  A pf_feed_device frame must stay valid until
+                                pf_sync in either case.                                                                      */
 } pf_options;
 
 typedef struct pf_map pf_map;

@@ -38,7 +38,8 @@ class Options(C.Structure):
     _fields_ = [("band_number", C.c_int), ("force_float", C.c_int), ("high_quality_show", C.c_int),
                 ("weight_type", C.c_int), ("bg_color", C.c_int), ("resolution", C.c_double),
                 ("scale", C.c_double), ("device", C.c_int), ("shard_rank", C.c_int),
-                ("shard_count", C.c_int), ("shard_block", C.c_int), ("max_queue", C.c_int), ("fused", C.c_int)]
+                ("shard_count", C.c_int), ("shard_block", C.c_int), ("max_queue", C.c_int), ("fused", C.c_int),
+                ("lookahead", C.c_int)]
 
 
 class Image(C.Structure):

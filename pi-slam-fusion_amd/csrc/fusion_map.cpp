@@ -180,6 +180,7 @@ FusionMap::FusionMap(int type, bool thread, const pf_options& opt) : opt_(opt), 
     table_in_args_ = exp_env("PF_TABLE_COPY") == nullptr;              // experiments library, PF_TABLE_COPY=1: every tile table staged and copied in the stream (A/B, tests)
     if (opt_.shard_count < 1) opt_.shard_count = 1;
     if (opt_.shard_block < 1) opt_.shard_block = 8;
+    opt_.lookahead = std::min(std::max(opt_.lookahead, 0), 64);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -290,7 +291,7 @@ void FusionMap::prof_harvest()
 
 int FusionMap::profile_read(int cap, const char** names, double* ms, long long* launches, double* bytes, double* bytes_run)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     (void)hipSetDevice(device_);
     (void)sync_all();
     prof_harvest();
@@ -304,7 +305,7 @@ int FusionMap::profile_read(int cap, const char** names, double* ms, long long* 
 
 void FusionMap::profile_reset()
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     (void)hipSetDevice(device_);
     (void)sync_all();
     prof_harvest();
@@ -327,13 +328,13 @@ bool FusionMap::reserve_tiles(long long n_tiles)
 
 void FusionMap::render_stats(double out[4])
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     out[0] = (double)n_with_pixels_; out[1] = px_level0_; out[2] = px_owned_; out[3] = (double)store_.size();
 }
 
 void FusionMap::stats(long long* rendered, long long* rejected, long long* dropped)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (rendered) *rendered = n_rendered_;
     if (rejected) *rejected = n_rejected_;
     std::lock_guard<std::mutex> q(qmu_);
@@ -392,6 +393,9 @@ bool FusionMap::prepare(const double plane7[7], const double cam[6], int n, cons
     }
     std::lock_guard<std::mutex> l(mu_);
     if (!set_device()) return false;
+    if (valid_) (void)drain();                 // keyframes fed against the old preparation are rendered into it, as they would have been inside their feed calls
+    for (auto& p : pending_) release_slot(p.f);
+    pending_.clear();
     HIP_OK(sync_all());
     store_.clear();
     plane_ = plane; plane_inv_ = pinv; cam_ = c;
@@ -423,7 +427,7 @@ int FusionMap::acquire_slot(size_t bytes)
 {
     // called with mu_ held.  A slot is reusable once it left the queue and the
     // kernels that read it have completed.
-    const size_t limit = (size_t)opt_.max_queue + 4;
+    const size_t limit = (size_t)opt_.max_queue + 4 + (size_t)opt_.lookahead;          // the feed queue, frames in flight, keyframes that wait for their lookahead
     for (int pass = 0; pass < 2; pass++) {
         int oldest_pending = -1;
         for (size_t i = 0; i < slots_.size(); i++) {
@@ -635,11 +639,17 @@ void FusionMap::worker()
         }
         {
             std::lock_guard<std::mutex> l(mu_);
-            if (valid_) render_frame(f);
+            if (valid_ && set_device()) render_frame(f);          // in; rendered once opt_.lookahead more keyframes are, or ...
+            else release_slot(f);
+        }
+        bool idle;
+        { std::lock_guard<std::mutex> q(qmu_); idle = queue_.empty(); }
+        if (idle) {                                               // ... now, when nothing else waits in the feed queue: no keyframe is held back for company that may never come
+            std::lock_guard<std::mutex> l(mu_);
+            (void)drain();
         }
         {
             std::lock_guard<std::mutex> q(qmu_);
-            if (f.slot >= 0) slots_[f.slot].queued = false;
             worker_busy_ = false;
         }
         idle_cv_.notify_all();
@@ -654,7 +664,7 @@ bool FusionMap::sync()
         idle_cv_.wait(q, [this] { return queue_.empty() && !worker_busy_; });
     }
     std::lock_guard<std::mutex> l(mu_);
-    if (!set_device()) return false;
+    if (!set_device() || !drain()) return false;
     HIP_OK(sync_all());
     prof_harvest();
     return true;
@@ -699,8 +709,94 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     Section sec(this, T_RENDER);
     FrameWork& w = fw_;
     w.reset();
+    // Geometry now, in feed order: the grid advances (spreadMap) and a keyframe is rejected inside its own feed call whether or not its
+    // pixels wait for the lookahead.
     const int go = frame_canvas(f, w);
-    if (go <= 0) { if (go < 0) n_rejected_++; return go == 0; }          // -1: rejected (.cpp:340-343, :381-386); 0: geometry-only frame
+    if (go <= 0) { release_slot(f); if (go < 0) n_rejected_++; return go == 0; }          // -1: rejected (.cpp:340-343, :381-386); 0: geometry-only frame
+    pending_.emplace_back();
+    PendingFrame& p = pending_.back();
+    p.f = f;
+    std::memcpy(p.pts, w.pts, sizeof(p.pts));
+    p.sx0 = w.xminInt + off_x_; p.sy0 = w.yminInt + off_y_; p.tx = w.tx; p.ty = w.ty;
+    std::memcpy(p.M0, w.M0, sizeof(p.M0));
+    // may this keyframe's cells be culled?  (the lattice of its canvas mapped into the source, if so)
+    w.cull = cull_on_ && (single_band_ || (opt_.fused == 1 && w.L >= 1)) && invert3x3(w.M0, w.Minv) && cull_frame_ok(w.Minv, w.crows, w.ccols);
+    p.cull = w.cull;
+    std::memcpy(p.Minv, w.Minv, sizeof(p.Minv));
+    if (f.slot >= 0) { std::lock_guard<std::mutex> q(qmu_); slots_[f.slot].queued = true; }      // held until the keyframe is rendered (retire_frame)
+    size_t keep = 0;
+    if (w.cull) {
+        if (lat_.sx.capacity() == 0 && !lat_pool_.empty()) { lat_ = std::move(lat_pool_.back()); lat_pool_.pop_back(); }
+        cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << w.L) - 2 + 63) / 64);
+        if (lookahead_ok()) {
+            // the keyframe's own lower bounds enter the tiles' wlb NOW: the keyframes ahead of it in the queue are decided against them
+            pre_raise(w);
+            keep = (size_t)opt_.lookahead;
+        }
+        std::swap(lat_, p.lat);
+    }
+    // a keyframe that cannot take part (no cull for it, a sharded / single-band / per-level map) is rendered at once, and everything before it
+    while (pending_.size() > keep)
+        if (!render_front()) return false;
+    return true;
+}
+
+// The weight bounds of an admitted keyframe (build_tile_table will find them again when it is rendered: wlb only ever rises).
+// Creates the canvas' tiles, as Apply's tile loop does (.cpp:478-492).
+void FusionMap::pre_raise(FrameWork& w)
+{
+    const int S = cull_sub_, span = 4 / S;
+    for (int y = 0; y < w.ty; y++)
+        for (int x = 0; x < w.tx; x++) {
+            Tile* t = store_.get_or_create(w.xminInt + x + off_x_, w.yminInt + y + off_y_);
+            if (!t) return;                                   // HBM exhausted: render_front reports it
+            for (int q = 0; q < S * S; q++) {
+                float wmin;
+                (void)cell_out(4 * x + span * (q % S), 4 * y + span * (q / S), span, opt_.weight_type, t->wlb[q], false, &wmin);
+                if (wmin > t->wlb[q]) t->wlb[q] = wmin;
+            }
+        }
+}
+
+void FusionMap::release_slot(const QueuedFrame& f)
+{
+    if (f.slot < 0) return;
+    std::lock_guard<std::mutex> q(qmu_);
+    slots_[f.slot].queued = false;
+}
+
+bool FusionMap::drain()
+{
+    if (pending_.empty()) return true;
+    if (!set_device()) return false;
+    while (!pending_.empty())
+        if (!render_front()) return false;
+    return true;
+}
+
+// stages 4 onwards of renderFrame for the oldest keyframe that waits
+bool FusionMap::render_front()
+{
+    struct Pop {            // the keyframe leaves the queue whatever happens to it (its lattice stays in lat_: the next admission writes over it)
+        FusionMap* m;
+        ~Pop() {
+            PendingFrame& p = m->pending_.front();
+            if (p.lat.sx.capacity() && m->lat_pool_.size() < 8) m->lat_pool_.push_back(std::move(p.lat));
+            m->pending_.pop_front();
+        }
+    } pop{ this };
+    PendingFrame& p = pending_.front();
+    const QueuedFrame f = p.f;
+    struct Held { FusionMap* m; const QueuedFrame& f; bool done = false; ~Held() { if (!done) m->release_slot(f); } } held{ this, f };
+    FrameWork& w = fw_;
+    w.reset();
+    std::memcpy(w.pts, p.pts, sizeof(p.pts));
+    w.xminInt = p.sx0 - off_x_; w.yminInt = p.sy0 - off_y_; w.xmaxInt = w.xminInt + p.tx; w.ymaxInt = w.yminInt + p.ty;
+    w.tx = p.tx; w.ty = p.ty; w.L = band_num_; w.crows = w.ty * kElePixels; w.ccols = w.tx * kElePixels;
+    std::memcpy(w.M0, p.M0, sizeof(p.M0)); std::memcpy(w.Minv, p.Minv, sizeof(p.Minv));
+    w.cull = p.cull;
+    w.src = f.ext ? f.ext : slots_[f.slot].dev;
+    if (p.cull) std::swap(lat_, p.lat);
     Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
     if (!build_tile_table(f, w)) return false;
     if (w.bx0 >= w.bx1) {                      // nothing of this frame lands on this shard, or it cannot win anywhere it lands
@@ -732,6 +828,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     } else ok = launch_per_op(f, w);
     if (!ok) return false;
     HIP_OK(hipGetLastError());
+    held.done = true;                          // retire_frame hands the slot over to its consumed event
     return retire_frame(f, w, fused);
 }
 
@@ -802,17 +899,16 @@ int FusionMap::frame_canvas(const QueuedFrame& f, FrameWork& w)
 // not look at their pixels (kernels.hip, cell_culled), which may have been computed from input nobody produced.
 bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
 {
-    const int tx = w.tx, ty = w.ty, L = w.L;
+    const int tx = w.tx, ty = w.ty;
     w.sharded = opt_.shard_count > 1;
     const bool sharded = w.sharded;
-    w.cull = cull_on_ && (single_band_ || (opt_.fused == 1 && L >= 1)) && invert3x3(w.M0, w.Minv) && cull_frame_ok(w.Minv, w.crows, w.ccols);
-    const bool cull = w.cull;
+    const bool cull = w.cull;                                    // decided when the keyframe was admitted (render_frame), with its lattice (lat_)
+    const bool lookahead = cull && lookahead_ok();
     const int S = cull_sub_, span = 4 / S;                       // cells per tile edge; lattice steps per cell
     if (cull) w.raise.reserve((size_t)tx * ty * S * S);
     // Map2DCPU (single band, round 6): no pyramid, so a cell is not dilated; the bounds are those of the radial weight all the same, compared
     // three alpha steps apart -- the stored alpha byte is floor(254 w) (at least 2) interpolated with 15-bit taps (within 1 of its smallest
     // tap), the select is `ele.a < dst.a` (Map2DCPU.cpp:326-327): the keyframe cannot win where 254 wmax <= 254 wlb - 3.
-    if (cull) cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << L) - 2 + 63) / 64);
     const float sb_gap = single_band_ ? 3.2f / 254.f : 0.f, sb_floor = single_band_ ? 6.f / 254.f : 0.f;
     auto stored_bound = [&](float wlb) { return wlb > sb_floor ? wlb - sb_gap : 0.f; };      // what cell_out compares the keyframe's weights with
     const int B = opt_.shard_block;
@@ -851,8 +947,14 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
                 if (cull) {
                     // the whole tile first, against the smallest of its cells' bounds: out there is out in every cell (the tile's dilated
                     // rectangle holds each cell's) -- most culled cells lie in such tiles, and only their wmin is still worked out
+                    // A FRESH tile (no keyframe has written it: its first one copies unconditionally, .cpp:498) is rendered whole or not at
+                    // all: its slot holds no weights a select could be run against, so no single cell may be left out.  It can be left out
+                    // whole only through the lookahead -- its wlb then holds bounds of keyframes that wait behind this one; the one whose
+                    // bound is the largest in a cell is never out there and renders the tile (all of it) before anybody looks.  Without
+                    // lookahead a fresh tile's wlb is -1 and nothing is out.
                     bool tile_out = false;
-                    if (!t->fresh) {
+                    const bool ask = !t->fresh || lookahead;
+                    if (ask) {
                         float wl = t->wlb[0], unused;
                         for (int q = 1; q < S * S; q++) wl = std::min(wl, t->wlb[q]);
                         tile_out = cell_out(4 * x, 4 * y, 4, opt_.weight_type, stored_bound(wl), true, &unused);
@@ -860,9 +962,15 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
                     for (int q = 0; q < S * S; q++) {
                         const int qx = q % S, qy = q / S;
                         float wmin;
-                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, stored_bound(t->wlb[q]), !t->fresh && !tile_out, &wmin) || tile_out)
+                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, stored_bound(t->wlb[q]), ask && !tile_out, &wmin) || tile_out)
                             out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
                         if (wmin > t->wlb[q]) w.raise.push_back(FrameWork::Raise{ t, q, wmin });
+                    }
+                    if (t->fresh && out != 0xffffu) out = 0;
+                    if (out == 0xffffu && t->fresh) {
+                        // stays fresh, and is not yet a tile of the mosaic (no Ischanged: it has no pyramid, .cpp:717-718)
+                        w.culled_any = true; table_tmp_[(size_t)y * tx + x] = 0; n_culled_tiles_++;
+                        continue;
                     }
                     if (out == 0xffffu) {
                         // not rendered, but still a tile of this keyframe's canvas: Apply sets Ischanged on every one of them
@@ -1311,7 +1419,12 @@ bool FusionMap::retire_frame(const QueuedFrame& f, FrameWork& w, bool fused)
         if (!submitted()) return false;
         table_release_[w.ring] = work_no_;
     }
-    if (f.slot >= 0) { HIP_OK(hipEventRecord(slots_[f.slot].consumed, stream_)); slots_[f.slot].pending = true; }
+    if (f.slot >= 0) {
+        const hipError_t e = hipEventRecord(slots_[f.slot].consumed, stream_);
+        slots_[f.slot].pending = e == hipSuccess;
+        release_slot(f);                           // no longer held by the queue: reusable once `consumed` has passed
+        HIP_OK(e);
+    }
     for (Tile* t : w.touched) { t->fresh = false; t->changed = true; }
     for (Tile* t : w.culled) t->changed = true;
     for (auto& r : w.raise) r.t->wlb[r.q] = std::max(r.t->wlb[r.q], r.w);
@@ -1367,7 +1480,7 @@ void FusionMap::cull_exact_stat(const FrameWork& w)
 
 int FusionMap::render_log(long long* out, int cap)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     const int n = (int)std::min<size_t>(render_log_.size(), (size_t)std::max(cap, 0));
     for (int i = 0; i < n; i++) out[i] = render_log_[render_log_.size() - (size_t)n + (size_t)i];
     return (int)render_log_.size();
@@ -1598,7 +1711,7 @@ bool FusionMap::grid(int dims[4], double geo[6])
 
 bool FusionMap::map_update_inputs(int ix, int iy, double plane7[7], double mn[2], double* ele, int* x, int* y)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!valid_) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;                            // .cpp:717-718: no pyramid yet
@@ -1612,7 +1725,7 @@ bool FusionMap::map_update_inputs(int ix, int iy, double plane7[7], double mn[2]
 
 int FusionMap::tile_count()
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     int n = 0;
     store_.for_each([&](int, int, Tile& t) { if (!t.fresh) n++; });
     return n;
@@ -1620,7 +1733,7 @@ int FusionMap::tile_count()
 
 int FusionMap::tile_coords(int* xy, int cap)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     std::vector<std::pair<int, int>> v;
     store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) v.push_back({ iy, ix }); });
     std::sort(v.begin(), v.end());
@@ -1630,7 +1743,7 @@ int FusionMap::tile_coords(int* xy, int cap)
 
 bool FusionMap::get_tile_bgra(int ix, int iy, uint8_t* bgra)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !single_band_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
@@ -1641,7 +1754,7 @@ bool FusionMap::get_tile_bgra(int ix, int iy, uint8_t* bgra)
 
 bool FusionMap::get_tile_level(int ix, int iy, int level, void* lap, float* w)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || single_band_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh || level < 0 || level > band_num_) return false;
@@ -1654,7 +1767,7 @@ bool FusionMap::get_tile_level(int ix, int iy, int level, void* lap, float* w)
 
 bool FusionMap::halo_pack(int ix, int iy, int dx, int dy, void* dev_out)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
@@ -1665,7 +1778,7 @@ bool FusionMap::halo_pack(int ix, int iy, int dx, int dy, void* dev_out)
 
 bool FusionMap::tile_export(int ix, int iy, void* dev_out)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
@@ -1676,7 +1789,7 @@ bool FusionMap::tile_export(int ix, int iy, void* dev_out)
 
 bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !valid_ || !set_device()) return false;
     Tile* t = store_.get_or_create(ix, iy);
     if (!t) return false;
@@ -1690,7 +1803,7 @@ bool FusionMap::tile_import(int ix, int iy, const void* dev_in)
 // ------------------------------------------------------- seam exchange support (dist.cpp)
 void FusionMap::list_tiles(std::vector<TileRec>& out)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     out.clear();
     store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh) out.push_back({ ix, iy, t.changed ? 1 : 0 }); });
     std::sort(out.begin(), out.end(), [](const TileRec& a, const TileRec& b) { return a.iy != b.iy ? a.iy < b.iy : a.ix < b.ix; });
@@ -1699,7 +1812,7 @@ void FusionMap::list_tiles(std::vector<TileRec>& out)
 // every strip set of one exchange: one descriptor upload, one launch, no sync (the caller orders its transport after stream_)
 bool FusionMap::pack_strips(const std::vector<StripReq>& reqs, void* dev_out)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     if (reqs.empty()) return true;
     if (!settle()) return false;
@@ -1720,7 +1833,7 @@ bool FusionMap::pack_strips(const std::vector<StripReq>& reqs, void* dev_out)
 // whole tiles (pyramids + weights) of this rank, back to back in dev_out, for save()'s gather
 bool FusionMap::export_tiles(const std::vector<std::pair<int, int>>& tiles, void* dev_out)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     if (!settle()) return false;
     for (size_t i = 0; i < tiles.size(); i++) {
@@ -1735,7 +1848,7 @@ bool FusionMap::export_tiles(const std::vector<std::pair<int, int>>& tiles, void
 // the changed tiles among `tiles` blended with remote strips; clears their Ischanged flags (draw(), .cpp:705-742)
 bool FusionMap::blend_tiles(const std::vector<std::pair<int, int>>& tiles, const void* const* halo9, uint8_t* bgr)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device() || single_band_) return false;
     if (!blend_batch(tiles, halo9, nullptr, bgr)) return false;
     for (auto& t : tiles) { Tile* q = store_.find(t.first, t.second); if (q) q->changed = false; }
@@ -1999,7 +2112,7 @@ bool FusionMap::blend_tile(int ix, int iy, void* raw, uint8_t* bgr, const void* 
         if (bgr) for (size_t i = 0; i < (size_t)kElePixels * kElePixels; i++) { bgr[3 * i] = px[4 * i]; bgr[3 * i + 1] = px[4 * i + 1]; bgr[3 * i + 2] = px[4 * i + 2]; }
         return true;
     }
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     Tile* t = store_.find(ix, iy);
     if (!t || t->fresh) return false;
@@ -2013,7 +2126,7 @@ bool FusionMap::blend_list(const std::vector<std::pair<int, int>>& tiles, uint8_
         for (size_t i = 0; i < tiles.size(); i++) (void)blend_tile(tiles[i].first, tiles[i].second, nullptr, bgr + i * (size_t)kElePixels * kElePixels * 3, nullptr);
         return init_ok_;
     }
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return false;
     return blend_batch(tiles, nullptr, nullptr, bgr);
 }
@@ -2021,7 +2134,7 @@ bool FusionMap::blend_list(const std::vector<std::pair<int, int>>& tiles, uint8_
 // the draw() loop's texture refresh (.cpp:705-742) without GL
 int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !set_device()) return 0;
     std::vector<std::pair<int, int>> v;
     store_.for_each([&](int ix, int iy, Tile& t) { if (!t.fresh && t.changed) v.push_back({ iy, ix }); });
@@ -2058,7 +2171,7 @@ int FusionMap::blend_changed(int* xy, uint8_t* bgr, int cap)
 // the whole mosaic once, 8U, background where level-0 weight is 0.
 bool FusionMap::save_to_memory(uint8_t* bgr, int* rows, int* cols, int* tx0, int* ty0, const std::vector<ForeignTile>* foreign)
 {
-    std::lock_guard<std::mutex> l(mu_);
+    std::lock_guard<std::mutex> l(mu_); (void)drain();
     if (!init_ok_ || !valid_ || !set_device()) return false;
     if (w_ == 0 || h_ == 0) return false;
     Section sec(this, T_SAVE);

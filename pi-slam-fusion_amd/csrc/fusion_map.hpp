@@ -136,9 +136,9 @@ public:
     void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil);
     size_t lattice_point(int k, int m);
     bool cell_out(int k, int m, int span, int weight_type, float wlb, bool want_out, float* wmin);
-    long long culled_tiles() const { return n_culled_tiles_; }
-    void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); cull_on_ = on; }       // default: on unless PF_CULL=0
-    long long culled_cells() const { return n_culled_cells_; }
+    long long culled_tiles() { std::lock_guard<std::mutex> l(mu_); (void)drain(); return n_culled_tiles_; }
+    void set_cull(bool on) { std::lock_guard<std::mutex> l(mu_); (void)drain(); cull_on_ = on; }       // default: on unless PF_CULL=0
+    long long culled_cells() { std::lock_guard<std::mutex> l(mu_); (void)drain(); return n_culled_cells_; }
     // test hook: the feed() calls (0-based, counted since creation) whose keyframes renderFrame accepted, in render order -- with thread = true
     // and a queue that drops, the only way to tell an oracle which keyframes the map really holds; the newest 65536
     int  render_log(long long* out, int cap);
@@ -216,7 +216,8 @@ private:
     double cull_margin_px_ = exp_env_double("PF_CULL_MARGIN_PX", 2.0);
     double cull_margin_w_ = exp_env_double("PF_CULL_MARGIN_W", 1e-5);
     int cull_sub_ = exp_env_int("PF_CULL_SUB", 4) == 2 ? 2 : 4;      // cells per tile edge (experiments library: 2 = quadrants)
-    struct { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; } lat_;
+    struct Lattice { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; };
+    Lattice lat_;                                   // of the keyframe being admitted / rendered
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;
     double min_[3]{}, max_[3]{};
@@ -294,6 +295,26 @@ private:
         }
     };
     FrameWork fw_;
+    // Keyframes that are in (geometry done, grid advanced, tiles created, their weight bounds raised) but not rendered yet: the LOOKAHEAD of the
+    // cull (round 6).  The max-weight select is order independent -- a pixel-level ends with the largest weight, the newest keyframe among equals
+    // (.cpp:521, :542 `>=`; a fresh tile's unconditional copy is the same select against weight 0) -- so a keyframe may be left out of a cell not
+    // only where an EARLIER keyframe's weights bound it from above (rounds 4-5) but also where a LATER one's do, provided that later keyframe is
+    // certain to be rendered before anybody looks: every reader of the map's state drains this queue first (drain()), so what a caller can
+    // observe after feed() k is exactly the map after keyframes 1..k.  opt_.lookahead keyframes wait here (0: render inside feed() as before).
+    struct PendingFrame {
+        QueuedFrame f;
+        double pts[8]; int sx0, sy0, tx, ty;        // canvas origin in STABLE tile coordinates (dense index + accumulated spreadMap offset)
+        double M0[9], Minv[9];
+        bool cull;
+        Lattice lat;                                // the cull's lattice of this keyframe (cull only)
+    };
+    std::deque<PendingFrame> pending_;
+    std::vector<Lattice> lat_pool_;                 // buffers of rendered keyframes' lattices, reused
+    bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && opt_.shard_count <= 1 && cull_on_; }
+    bool render_front();                            // renders pending_.front() and removes it
+    bool drain();                                   // ... all of them; mu_ held.  First thing every reader of tiles, flags or counters does
+    void release_slot(const QueuedFrame& f);
+    void pre_raise(FrameWork& w);
     int  frame_canvas(const QueuedFrame& f, FrameWork& w);
     bool build_tile_table(const QueuedFrame& f, FrameWork& w);
     void level_windows(FrameWork& w);
