@@ -105,10 +105,11 @@ def kernels_sha():
     return h.hexdigest()[:16]
 
 
-def window_key(steps, warmup, pre, no_cull=False):
+def window_key(steps, warmup, pre, no_cull=False, lookahead=None):
     """Names the launches a PMC pass averaged over: the K timed launches of `bench.py --steps K --warmup W` with `pre` keyframes of the
-    sortie flown before the warm-up (tools/pmc_summary.py takes the same three numbers)."""
-    return "k%d_w%d_pre%d%s" % (steps, warmup, pre, "_nocull" if no_cull else "")
+    sortie flown before the warm-up (tools/pmc_summary.py takes the same three numbers); a run with an explicit --lookahead is a window of
+    its own (the passes under profiles/ are taken at the library's default)."""
+    return "k%d_w%d_pre%d%s%s" % (steps, warmup, pre, "_nocull" if no_cull else "", "" if lookahead is None or no_cull else "_la%d" % lookahead)
 
 
 def pmc_record(dtype_key, kernel, window=None):
@@ -477,6 +478,9 @@ def main():
     ap.add_argument("--shard", choices=["weak", "strong"], default="weak")
     ap.add_argument("--shard-block", type=int, default=None, help="spatial-hash cell edge in tiles (weak: 128, strong: 8)")
     ap.add_argument("--no-cull", action="store_true", help="render every tile of every keyframe's canvas (PF_CULL=0): the full_render_no_cull sub-record")
+    ap.add_argument("--lookahead", type=int, default=None,
+                    help="pf_options.lookahead: keyframes that wait, fed but not rendered, so that the cull knows the next ones' weight bounds "
+                         "(default: the library's, 4; 0 = every keyframe rendered inside its feed call, the engine of rounds 1-5)")
     ap.add_argument("--no-pre", action="store_true",
                     help="do not fly the 20 - W keyframes of the sortie's first line before the warm-up: a short run then times that "
                          "first line (every tile new, nothing culled), as round 2's driver record did")
@@ -517,6 +521,8 @@ def main():
     PRE = 0 if args.no_pre else (max(0, 20 - W) if args.pre is None else max(0, args.pre))
     n_traj = K + W + PRE
     extra = {} if args.fused is None else {"fused": args.fused}
+    if args.lookahead is not None:
+        extra["lookahead"] = args.lookahead
 
     def make_map(ff):
         opt = pf.default_options(force_float=ff, scale=args.scale, device=dev,
@@ -636,6 +642,8 @@ def main():
                        "tile_sharding": "none" if N == 1 else
                                         ("one sortie, tiles split by spatial hash, cell %d tiles" % block if strong else
                                          "replicas: one sortie per rank inside its own hash cell (cell %d tiles)" % block),
+                       # keyframes that wait for the cull's lookahead (pf_options.lookahead; every one of them is rendered before the closing sync)
+                       "lookahead": int(opt.lookahead),
                        "rendered_rank0": st["rendered"],
                        # tiles of the timed keyframes' canvases left out of the launches because the keyframe cannot win the max-weight
                        # select anywhere in them (geometric bound, results identical to the full render; PF_CULL=0 renders them all)
@@ -645,7 +653,7 @@ def main():
                        # count the bytes of what the launches' blocks processed (alg_bytes_run), frac_full_canvas SURVEY 8d's bytes for EVERY tile
                        # of every canvas, roofline.traffic / frac_delivered what moved
                        **canvas_shares(m)},
-            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0 and N == 1, window_key(K, W, PRE, args.no_cull)),
+            "roofline": guarded(roofline_record, dom, p, dkey, ev_every, args.scale == 1.0 and N == 1, window_key(K, W, PRE, args.no_cull, args.lookahead)),
             # the same bytes over the whole step instead of the launches bracketed by events: launches run back to back (gap 0 in the
             # rocprofv3 trace), so a step IS a launch, and an event pair costs the launch it brackets several us (N = 1 only)
             "roofline_per_step": None,
@@ -704,6 +712,16 @@ def main():
             j = json.loads(r.stdout.decode().strip().splitlines()[-1])
             return {"value": j["value"], "unit": "keyframes/s", "dtype": j["dtype"], "ms_per_step": j["ms_per_step"],
                     "culled_tiles": j["config"]["culled_tiles_rank0"], "roofline": j["roofline"]}
+        def no_lookahead():
+            cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--lookahead", "0", "--steps", str(K), "--warmup", str(W), "--scale", str(args.scale)]
+            if args.int16:
+                cmd.append("--int16")
+            if args.no_pre:
+                cmd.append("--no-pre")
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            return {"value": j["value"], "unit": "keyframes/s", "dtype": j["dtype"], "ms_per_step": j["ms_per_step"],
+                    "culled_tiles": j["config"]["culled_tiles_rank0"], "rendered_share": j["config"].get("rendered_share_rank0"), "roofline": j["roofline"]}
         def other_dtype():
             m2, _ = make_map(1 - force_float)
             assert m2.prepare(wl.IDENTITY_PLANE, CAM, prep)
@@ -713,11 +731,14 @@ def main():
             dt2, dom2, p2, _ = timed_run(m2, make_run(m2), W, K, ev_every, barrier)
             k2 = "f32" if not force_float else "int16"
             rec = {"value": round(K / dt2, 3), "unit": "keyframes/s", "dtype": k2, "ms_per_step": round(dt2 / K * 1e3, 4),
-                   "roofline": roofline_record(dom2, p2, k2, ev_every, args.scale == 1.0, window_key(K, W, PRE, args.no_cull))}
+                   "roofline": roofline_record(dom2, p2, k2, ev_every, args.scale == 1.0, window_key(K, W, PRE, args.no_cull, args.lookahead))}
             m2.close()
             return rec
         out["int16" if force_float else "f32"] = guarded(other_dtype)
         out["full_render_no_cull"] = guarded(full_render)
+        if int(opt.lookahead) > 0 and not args.no_cull:
+            # every keyframe rendered inside its own feed call (the engine of rounds 1-5): what the lookahead of the cull buys
+            out["no_lookahead"] = guarded(no_lookahead)
 
 
     if rank == 0 and not args.no_cpu:

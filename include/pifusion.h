@@ -62,8 +62,8 @@ typedef struct pf_options {
                                 keyframe is rendered inside its own feed call).  The select keeps the largest weight, the newest
                                 keyframe among equals, whatever the order, and every call that reads tiles, flags or counters
                                 (pf_sync, blend, save, tile access, statistics) renders what waits first: what a caller can observe
-                                is the map after the keyframes fed so far, exactly as without it.  Unsharded multi-band maps
-                                with fused = 1; elsewhere the value is ignored.  A pf_feed_device frame must stay valid until
+                                is the map after the keyframes fed so far, exactly as without it.  Multi-band maps with
+                                fused = 1 (a shard looks ahead among its own tiles); elsewhere the value is ignored.  A pf_feed_device frame must stay valid until
                                 pf_sync in either case.                                                                      */
 } pf_options;
 

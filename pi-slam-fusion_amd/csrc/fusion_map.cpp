@@ -746,9 +746,12 @@ bool FusionMap::render_frame(const QueuedFrame& f)
 void FusionMap::pre_raise(FrameWork& w)
 {
     const int S = cull_sub_, span = 4 / S;
+    const bool sharded = opt_.shard_count > 1;
     for (int y = 0; y < w.ty; y++)
         for (int x = 0; x < w.tx; x++) {
-            Tile* t = store_.get_or_create(w.xminInt + x + off_x_, w.yminInt + y + off_y_);
+            const int sx = w.xminInt + x + off_x_, sy = w.yminInt + y + off_y_;
+            if (sharded && tile_owner(opt_.shard_count, opt_.shard_block, sx, sy) != opt_.shard_rank) continue;
+            Tile* t = store_.get_or_create(sx, sy);
             if (!t) return;                                   // HBM exhausted: render_front reports it
             for (int q = 0; q < S * S; q++) {
                 float wmin;

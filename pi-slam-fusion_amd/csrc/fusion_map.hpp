@@ -310,7 +310,7 @@ private:
     };
     std::deque<PendingFrame> pending_;
     std::vector<Lattice> lat_pool_;                 // buffers of rendered keyframes' lattices, reused
-    bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && opt_.shard_count <= 1 && cull_on_; }
+    bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && cull_on_; }
     bool render_front();                            // renders pending_.front() and removes it
     bool drain();                                   // ... all of them; mu_ held.  First thing every reader of tiles, flags or counters does
     void release_slot(const QueuedFrame& f);
