@@ -731,7 +731,9 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         if (lookahead_ok()) {
             // the keyframe's own lower bounds enter the tiles' wlb NOW: the keyframes ahead of it in the queue are decided against them
             pre_raise(w);
-            keep = (size_t)opt_.lookahead;
+            p.pre_raised = true;
+            since_drain_++;
+            keep = std::min<size_t>((size_t)opt_.lookahead, 2 * (size_t)since_drain_ / 3);
         }
         std::swap(lat_, p.lat);
     }
@@ -745,6 +747,7 @@ bool FusionMap::render_frame(const QueuedFrame& f)
 // Creates the canvas' tiles, as Apply's tile loop does (.cpp:478-492).
 void FusionMap::pre_raise(FrameWork& w)
 {
+
     const int S = cull_sub_, span = 4 / S;
     const bool sharded = opt_.shard_count > 1;
     for (int y = 0; y < w.ty; y++)
@@ -770,6 +773,7 @@ void FusionMap::release_slot(const QueuedFrame& f)
 
 bool FusionMap::drain()
 {
+    since_drain_ = 0;
     if (pending_.empty()) return true;
     if (!set_device()) return false;
     while (!pending_.empty())
@@ -798,6 +802,7 @@ bool FusionMap::render_front()
     w.tx = p.tx; w.ty = p.ty; w.L = band_num_; w.crows = w.ty * kElePixels; w.ccols = w.tx * kElePixels;
     std::memcpy(w.M0, p.M0, sizeof(p.M0)); std::memcpy(w.Minv, p.Minv, sizeof(p.Minv));
     w.cull = p.cull;
+    w.pre_raised = p.pre_raised;
     w.src = f.ext ? f.ext : slots_[f.slot].dev;
     if (p.cull) std::swap(lat_, p.lat);
     Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
@@ -962,10 +967,11 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
                         for (int q = 1; q < S * S; q++) wl = std::min(wl, t->wlb[q]);
                         tile_out = cell_out(4 * x, 4 * y, 4, opt_.weight_type, stored_bound(wl), true, &unused);
                     }
-                    for (int q = 0; q < S * S; q++) {
+                    if (tile_out && w.pre_raised) out = 0xffffu;       // (the keyframe's own bounds are in wlb since it was admitted)
+                    else for (int q = 0; q < S * S; q++) {
                         const int qx = q % S, qy = q / S;
-                        float wmin;
-                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, stored_bound(t->wlb[q]), ask && !tile_out, &wmin) || tile_out)
+                        float wmin = 0.f;
+                        if (cell_out(4 * x + span * qx, 4 * y + span * qy, span, opt_.weight_type, stored_bound(t->wlb[q]), ask && !tile_out, w.pre_raised ? nullptr : &wmin) || tile_out)
                             out |= S == 4 ? 1u << q : 0x33u << (8 * qy + 2 * qx);
                         if (wmin > t->wlb[q]) w.raise.push_back(FrameWork::Raise{ t, q, wmin });
                     }
@@ -1567,18 +1573,20 @@ bool FusionMap::cell_out(int k, int m, int span, int weight_type, float wlb, boo
     const int e = span + 2 * lat_.dil;                          // lattice steps across the dilated cell
     const size_t c[4] = { lattice_point(k, m), lattice_point(k + e, m), lattice_point(k + e, m + e), lattice_point(k, m + e) };
     const double d2[4] = { lat_.d[c[0]], lat_.d[c[1]], lat_.d[c[2]], lat_.d[c[3]] };
-    *wmin = 0.f;
-    // (weight type 0: wmin can exceed wlb only if the farthest corner lies within (1 - 1e-5 - wlb) dis_max - 2 of the centre -- in the steady
-    // state it rarely does, and the square root is not taken)
-    const double far2 = std::max(std::max(d2[0], d2[1]), std::max(d2[2], d2[3]));
     const double mpx = cull_margin_px_, mw = cull_margin_w_;       // 2 source pixels, 1e-5 (see the header)
-    const double tw = weight_type == 0 ? (1.0 - mw - (double)wlb) * lat_.dis_max - mpx : 1e300;
-    if ((lat_.in[c[0]] & lat_.in[c[1]] & lat_.in[c[2]] & lat_.in[c[3]]) == 1 && tw > 0 && far2 < tw * tw * (1.0 + 1e-9)) {
-        const double dfar = std::sqrt(far2) + mpx;
-        double w = 1.0 - dfar * lat_.inv_dis_max;
-        if (weight_type != 0) w = w > 0 ? w * w : 0.0;
-        w -= mw;
-        if (w > 2e-5) *wmin = (float)w;
+    if (wmin) {                                                    // (nullptr: only the question whether the cell is out)
+        *wmin = 0.f;
+        // (weight type 0: wmin can exceed wlb only if the farthest corner lies within (1 - 1e-5 - wlb) dis_max - 2 of the centre -- in the steady
+        // state it rarely does, and the square root is not taken)
+        const double far2 = std::max(std::max(d2[0], d2[1]), std::max(d2[2], d2[3]));
+        const double tw = weight_type == 0 ? (1.0 - mw - (double)wlb) * lat_.dis_max - mpx : 1e300;
+        if ((lat_.in[c[0]] & lat_.in[c[1]] & lat_.in[c[2]] & lat_.in[c[3]]) == 1 && tw > 0 && far2 < tw * tw * (1.0 + 1e-9)) {
+            const double dfar = std::sqrt(far2) + mpx;
+            double w = 1.0 - dfar * lat_.inv_dis_max;
+            if (weight_type != 0) w = w > 0 ? w * w : 0.0;
+            w -= mw;
+            if (w > 2e-5) *wmin = (float)w;
+        }
     }
     if (!want_out || !(wlb > 2e-5f)) return false;                // nothing known about the stored weights (or a fresh tile): in
     // T: weight(T - mpx) + mw == wlb

@@ -274,6 +274,7 @@ private:
         const uint8_t* src;
         // build_tile_table(): the cull, the owned tiles and their boxes (tiles; level-0 pixels), the hash cells of the need rectangles
         bool sharded, cull, culled_any, cells_overflow;
+        bool pre_raised;                                          // the keyframe's bounds entered wlb when it was admitted (lookahead): not worked out again
         struct Raise { Tile* t; int q; float w; };                // (cell, wmin of this keyframe): applied once the frame is in
         std::vector<Raise> raise; std::vector<Tile*> culled, touched;
         struct Cell { int cx, cy, x0, y0, x1, y1; };              // hash cell; box of what is rendered in it, level-0 pixels
@@ -291,7 +292,7 @@ private:
             raise.clear(); culled.clear(); touched.clear();
             culled_any = cells_overflow = false; ncells = 0; owned = owned_all = 0; blocks_run0 = 0;
             for (int i = 0; i < kMaxLevels; i++) { nrect[i] = 0; need_n[i] = 0; }
-            src = nullptr; ring = 0; table_args = false; dtab = nullptr; sharded = cull = false;
+            src = nullptr; ring = 0; table_args = false; dtab = nullptr; sharded = cull = pre_raised = false;
         }
     };
     FrameWork fw_;
@@ -307,8 +308,13 @@ private:
         double M0[9], Minv[9];
         bool cull;
         Lattice lat;                                // the cull's lattice of this keyframe (cull only)
+        bool pre_raised = false;                    // lookahead: the keyframe's lower bounds entered the tiles' wlb when it was admitted
     };
     std::deque<PendingFrame> pending_;
+    // The window FILLS at two keyframes per three feeds after it was last emptied (a reader, pf_sync): the first keyframe behind a sync is
+    // rendered at once and every third one after it (an admission costs the host ~25 us, a launch keeps the GPU busy for ~90), so the GPU
+    // does not idle while `lookahead` keyframes gather, and a short burst between two readers is not held up
+    unsigned since_drain_ = 0;
     std::vector<Lattice> lat_pool_;                 // buffers of rendered keyframes' lattices, reused
     bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && cull_on_; }
     bool render_front();                            // renders pending_.front() and removes it
