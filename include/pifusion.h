@@ -58,7 +58,7 @@ typedef struct pf_options {
                                 0: one kernel per reference op (warp / pyrDown /
                                 Laplacian+select)                                    */
     int    lookahead;        /* keyframes that wait, fed but not rendered, so that the cull can leave a keyframe out of the cells
-                                in which one of the NEXT `lookahead` keyframes is bound to overwrite it (default 8; 0: every
+                                in which one of the NEXT `lookahead` keyframes is bound to overwrite it (default 4; 0: every
                                 keyframe is rendered inside its own feed call).  The select keeps the largest weight, the newest
                                 keyframe among equals, whatever the order, and every call that reads tiles, flags or counters
                                 (pf_sync, blend, save, tile access, statistics) renders what waits first (the window then fills

@@ -730,7 +730,8 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << w.L) - 2 + 63) / 64);
         if (lookahead_ok()) {
             // the keyframe's own lower bounds enter the tiles' wlb NOW: the keyframes ahead of it in the queue are decided against them
-            pre_raise(w);
+            if (!tiles_pool_.empty()) { p.tiles = std::move(tiles_pool_.back()); tiles_pool_.pop_back(); }
+            pre_raise(w, p.tiles);
             p.pre_raised = true;
             since_drain_++;
             keep = std::min<size_t>((size_t)opt_.lookahead, 2 * (size_t)since_drain_ / 3);
@@ -745,8 +746,9 @@ bool FusionMap::render_frame(const QueuedFrame& f)
 
 // The weight bounds of an admitted keyframe (build_tile_table will find them again when it is rendered: wlb only ever rises).
 // Creates the canvas' tiles, as Apply's tile loop does (.cpp:478-492).
-void FusionMap::pre_raise(FrameWork& w)
+void FusionMap::pre_raise(FrameWork& w, std::vector<Tile*>& tiles)
 {
+    tiles.assign((size_t)w.tx * w.ty, nullptr);
 
     const int S = cull_sub_, span = 4 / S;
     const bool sharded = opt_.shard_count > 1;
@@ -755,7 +757,8 @@ void FusionMap::pre_raise(FrameWork& w)
             const int sx = w.xminInt + x + off_x_, sy = w.yminInt + y + off_y_;
             if (sharded && tile_owner(opt_.shard_count, opt_.shard_block, sx, sy) != opt_.shard_rank) continue;
             Tile* t = store_.get_or_create(sx, sy);
-            if (!t) return;                                   // HBM exhausted: render_front reports it
+            if (!t) { tiles.clear(); return; }                // HBM exhausted: build_tile_table meets it again and reports it
+            tiles[(size_t)y * w.tx + x] = t;                  // (references into the store stay valid while it grows)
             for (int q = 0; q < S * S; q++) {
                 float wmin;
                 (void)cell_out(4 * x + span * (q % S), 4 * y + span * (q / S), span, opt_.weight_type, t->wlb[q], false, &wmin);
@@ -789,6 +792,7 @@ bool FusionMap::render_front()
         ~Pop() {
             PendingFrame& p = m->pending_.front();
             if (p.lat.sx.capacity() && m->lat_pool_.size() < 8) m->lat_pool_.push_back(std::move(p.lat));
+            if (p.tiles.capacity() && m->tiles_pool_.size() < 8) m->tiles_pool_.push_back(std::move(p.tiles));
             m->pending_.pop_front();
         }
     } pop{ this };
@@ -803,6 +807,7 @@ bool FusionMap::render_front()
     std::memcpy(w.M0, p.M0, sizeof(p.M0)); std::memcpy(w.Minv, p.Minv, sizeof(p.Minv));
     w.cull = p.cull;
     w.pre_raised = p.pre_raised;
+    w.tiles_known = p.tiles.size() == (size_t)p.tx * p.ty ? p.tiles.data() : nullptr;
     w.src = f.ext ? f.ext : slots_[f.slot].dev;
     if (p.cull) std::swap(lat_, p.lat);
     Section sec_apply(this, T_APPLY);          // the reference times its tile loop under this name (.cpp:476-555); here: table, need rectangles, launch
@@ -947,8 +952,9 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
         for (int x = 0; x < tx; x++) {
             const int sx = w.xminInt + x + off_x_;
             uint64_t ent = 0;
-            if (!sharded || tile_owner(opt_.shard_count, B, sx, sy) == opt_.shard_rank) {
-                Tile* t = store_.get_or_create(sx, sy);
+            Tile* known = w.tiles_known ? w.tiles_known[(size_t)y * tx + x] : nullptr;
+            if (known || ((!sharded || tile_owner(opt_.shard_count, B, sx, sy) == opt_.shard_rank) && !w.tiles_known)) {
+                Tile* t = known ? known : store_.get_or_create(sx, sy);
                 if (!t) return false;
                 w.owned_all++;
                 unsigned out = 0;                                  // 64 x 64 cells in which this keyframe cannot win (bit 4 * row + column)

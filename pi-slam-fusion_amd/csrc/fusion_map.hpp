@@ -275,6 +275,7 @@ private:
         // build_tile_table(): the cull, the owned tiles and their boxes (tiles; level-0 pixels), the hash cells of the need rectangles
         bool sharded, cull, culled_any, cells_overflow;
         bool pre_raised;                                          // the keyframe's bounds entered wlb when it was admitted (lookahead): not worked out again
+        Tile* const* tiles_known;                                 // ... and its canvas' tiles are known from then (nullptr: look them up)
         struct Raise { Tile* t; int q; float w; };                // (cell, wmin of this keyframe): applied once the frame is in
         std::vector<Raise> raise; std::vector<Tile*> culled, touched;
         struct Cell { int cx, cy, x0, y0, x1, y1; };              // hash cell; box of what is rendered in it, level-0 pixels
@@ -292,7 +293,7 @@ private:
             raise.clear(); culled.clear(); touched.clear();
             culled_any = cells_overflow = false; ncells = 0; owned = owned_all = 0; blocks_run0 = 0;
             for (int i = 0; i < kMaxLevels; i++) { nrect[i] = 0; need_n[i] = 0; }
-            src = nullptr; ring = 0; table_args = false; dtab = nullptr; sharded = cull = pre_raised = false;
+            src = nullptr; ring = 0; table_args = false; dtab = nullptr; sharded = cull = pre_raised = false; tiles_known = nullptr;
         }
     };
     FrameWork fw_;
@@ -309,6 +310,7 @@ private:
         bool cull;
         Lattice lat;                                // the cull's lattice of this keyframe (cull only)
         bool pre_raised = false;                    // lookahead: the keyframe's lower bounds entered the tiles' wlb when it was admitted
+        std::vector<Tile*> tiles;                   // ... and the canvas' tiles were looked up / created then (row-major; nullptr: another shard's)
     };
     std::deque<PendingFrame> pending_;
     // The window FILLS at two keyframes per three feeds after it was last emptied (a reader, pf_sync): the first keyframe behind a sync is
@@ -316,11 +318,12 @@ private:
     // does not idle while `lookahead` keyframes gather, and a short burst between two readers is not held up
     unsigned since_drain_ = 0;
     std::vector<Lattice> lat_pool_;                 // buffers of rendered keyframes' lattices, reused
+    std::vector<std::vector<Tile*>> tiles_pool_;
     bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && cull_on_; }
     bool render_front();                            // renders pending_.front() and removes it
     bool drain();                                   // ... all of them; mu_ held.  First thing every reader of tiles, flags or counters does
     void release_slot(const QueuedFrame& f);
-    void pre_raise(FrameWork& w);
+    void pre_raise(FrameWork& w, std::vector<Tile*>& tiles);
     int  frame_canvas(const QueuedFrame& f, FrameWork& w);
     bool build_tile_table(const QueuedFrame& f, FrameWork& w);
     void level_windows(FrameWork& w);
