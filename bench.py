@@ -600,14 +600,18 @@ def main():
     else:
         need = [[owned_tiles(sorties[j][k])[0] > 0 for k in range(n_traj)] for j in range(N)]
 
+    # poses as the C ABI takes them, converted once: the feed loop is Python, and at N = 8 a rank makes eight calls a step
+    cposes = [[pf.POSE7(*[float(v) for v in p]) for p in s] for s in sorties]
+    ptrs = [f.data_ptr() for f in frames]
+
     def make_run(mm, shift=PRE):
         def run(lo, hi):
             for k in range(lo + shift, hi + shift):
                 for j in range(len(sorties)):
                     if need[j][k]:
-                        ok = mm.feed_device(frames[(k + j) % len(frames)].data_ptr(), 3000, 4000, sorties[j][k])
+                        ok = mm.feed_device(ptrs[(k + j) % len(ptrs)], 3000, 4000, cposes[j][k])
                     else:
-                        ok = mm.feed(None, sorties[j][k])
+                        ok = mm.feed(None, cposes[j][k])
                     assert ok, "frame %d of sortie %d rejected" % (k, j)
         return run
 

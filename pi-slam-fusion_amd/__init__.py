@@ -169,7 +169,12 @@ def lib():
     return L
 
 
+POSE7 = C.c_double * 7
+
+
 def _pose(p):
+    if isinstance(p, POSE7):          # a caller that feeds thousands of poses a second converts them once (bench.py)
+        return p, p
     a = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
     return a, a.ctypes.data_as(C.POINTER(C.c_double))
 

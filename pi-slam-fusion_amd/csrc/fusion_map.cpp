@@ -752,6 +752,41 @@ void FusionMap::pre_raise(FrameWork& w, std::vector<Tile*>& tiles)
 
     const int S = cull_sub_, span = 4 / S;
     const bool sharded = opt_.shard_count > 1;
+    if (!sharded && S == 4) {
+        // Unsharded: every lattice point is mapped (cull_lattice), every cell is asked.  The same arithmetic as cell_out's first half, without
+        // its calls: the farthest corner of a cell's dilated square from a pass that pairs the points e steps apart along a row first.
+        const int nx = lat_.nx, ny = lat_.ny, e = 1 + 2 * lat_.dil;
+        pair_d_.resize((size_t)nx * ny); pair_in_.resize((size_t)nx * ny);
+        for (int m = 0; m < ny; m++) {
+            const double* __restrict__ d = lat_.d.data() + (size_t)m * nx; const unsigned char* __restrict__ in = lat_.in.data() + (size_t)m * nx;
+            double* __restrict__ pd = pair_d_.data() + (size_t)m * nx; unsigned char* __restrict__ pi = pair_in_.data() + (size_t)m * nx;
+            for (int k = 0; k + e < nx; k++) { pd[k] = std::max(d[k], d[k + e]); pi[k] = in[k] & in[k + e]; }
+        }
+        const double mpx = cull_margin_px_, mw = cull_margin_w_;
+        const int wt = opt_.weight_type;
+        for (int y = 0; y < w.ty; y++)
+            for (int x = 0; x < w.tx; x++) {
+                Tile* t = store_.get_or_create(w.xminInt + x + off_x_, w.yminInt + y + off_y_);
+                if (!t) { tiles.clear(); return; }
+                tiles[(size_t)y * w.tx + x] = t;
+                for (int qy = 0; qy < 4; qy++) {
+                    const size_t r0 = (size_t)(4 * y + qy) * nx + 4 * x, r1 = r0 + (size_t)e * nx;
+                    for (int qx = 0; qx < 4; qx++) {
+                        if (!(pair_in_[r0 + qx] & pair_in_[r1 + qx])) continue;              // not wholly inside the frame: wmin 0
+                        float& wl = t->wlb[4 * qy + qx];
+                        const double far2 = std::max(pair_d_[r0 + qx], pair_d_[r1 + qx]);
+                        const double tw = wt == 0 ? (1.0 - mw - (double)wl) * lat_.dis_max - mpx : 1e300;
+                        if (!(tw > 0 && far2 < tw * tw * (1.0 + 1e-9))) continue;
+                        const double dfar = std::sqrt(far2) + mpx;
+                        double ww = 1.0 - dfar * lat_.inv_dis_max;
+                        if (wt != 0) ww = ww > 0 ? ww * ww : 0.0;
+                        ww -= mw;
+                        if (ww > 2e-5 && (float)ww > wl) wl = (float)ww;
+                    }
+                }
+            }
+        return;
+    }
     for (int y = 0; y < w.ty; y++)
         for (int x = 0; x < w.tx; x++) {
             const int sx = w.xminInt + x + off_x_, sy = w.yminInt + y + off_y_;
