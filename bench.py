@@ -480,7 +480,7 @@ def main():
     ap.add_argument("--no-cull", action="store_true", help="render every tile of every keyframe's canvas (PF_CULL=0): the full_render_no_cull sub-record")
     ap.add_argument("--lookahead", type=int, default=None,
                     help="pf_options.lookahead: keyframes that wait, fed but not rendered, so that the cull knows the next ones' weight bounds "
-                         "(default: the library's, 4; 0 = every keyframe rendered inside its feed call, the engine of rounds 1-5)")
+                         "(default: the library's, 48; 0 = every keyframe rendered inside its feed call, the engine of rounds 1-5)")
     ap.add_argument("--no-pre", action="store_true",
                     help="do not fly the 20 - W keyframes of the sortie's first line before the warm-up: a short run then times that "
                          "first line (every tile new, nothing culled), as round 2's driver record did")

@@ -58,13 +58,13 @@ typedef struct pf_options {
                                 0: one kernel per reference op (warp / pyrDown /
                                 Laplacian+select)                                    */
     int    lookahead;        /* keyframes that wait, fed but not rendered, so that the cull can leave a keyframe out of the cells
-                                in which one of the NEXT `lookahead` keyframes is bound to overwrite it (default 4; 0: every
+                                in which one of the NEXT `lookahead` keyframes is bound to overwrite it (default 48; 0: every
                                 keyframe is rendered inside its own feed call).  The select keeps the largest weight, the newest
                                 keyframe among equals, whatever the order, and every call that reads tiles, flags or counters
                                 (pf_sync, blend, save, tile access, statistics) renders what waits first (the window then fills
                                 again at two keyframes per three feeds, so the GPU is not left idle): what a caller can observe
                                 is the map after the keyframes fed so far, exactly as without it.  Multi-band maps with
-                                fused = 1 (a shard looks ahead among its own tiles); elsewhere the value is ignored.  A pf_feed_device frame must stay valid until
+                                fused = 1 and Map2DCPU maps (a shard looks ahead among its own tiles); elsewhere the value is ignored.  A pf_feed_device frame must stay valid until
                                 pf_sync in either case.                                                                      */
 } pf_options;
 

@@ -35,7 +35,7 @@ void pf_default_options(pf_options* o)
 {
     o->band_number = 5; o->force_float = 0; o->high_quality_show = 1; o->weight_type = 0; o->bg_color = 0;
     o->resolution = 0; o->scale = 1; o->device = -1; o->shard_rank = 0; o->shard_count = 1; o->shard_block = 8;
-    o->max_queue = 20; o->fused = 1; o->lookahead = 4;
+    o->max_queue = 20; o->fused = 1; o->lookahead = 48;
 }
 
 int pf_options_set(pf_options* o, const char* key, const char* value)

@@ -320,7 +320,7 @@ private:
     std::vector<Lattice> lat_pool_;                 // buffers of rendered keyframes' lattices, reused
     std::vector<std::vector<Tile*>> tiles_pool_;
     std::vector<double> pair_d_; std::vector<unsigned char> pair_in_;      // pre_raise scratch
-    bool lookahead_ok() const { return opt_.lookahead > 0 && !single_band_ && opt_.fused == 1 && band_num_ >= 1 && cull_on_; }
+    bool lookahead_ok() const { return opt_.lookahead > 0 && (single_band_ || (opt_.fused == 1 && band_num_ >= 1)) && cull_on_; }     // wherever the cull runs
     bool render_front();                            // renders pending_.front() and removes it
     bool drain();                                   // ... all of them; mu_ held.  First thing every reader of tiles, flags or counters does
     void release_slot(const QueuedFrame& f);

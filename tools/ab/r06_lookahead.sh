@@ -2,7 +2,7 @@
 # round 6: the cull's lookahead -- bench.py's cfg-A window (200 after 20, and the driver's 20 after 5) at lookahead 0 / 1 / 2 / 4 / 8 / 20, interleaved on one box
 out=gpurun_out/r06_lookahead; mkdir -p $out
 for rep in 1 2; do
-  for la in 0 8 2 4 20; do
+  for la in 0 48 4 8 20 32; do
     python3 bench.py --no-cpu --lookahead $la --steps 200 --warmup 20 > $out/f32_la${la}_r$rep.json 2>/dev/null
     python3 bench.py --no-cpu --lookahead $la --steps 200 --warmup 20 --int16 > $out/i16_la${la}_r$rep.json 2>/dev/null
     python3 bench.py --no-cpu --lookahead $la --steps 20 --warmup 5 > $out/drv_la${la}_r$rep.json 2>/dev/null
@@ -12,7 +12,7 @@ done
 python3 - <<'PY'
 import json,glob
 for kind in ("f32","i16","drv"):
-    for la in (0,2,4,8,20):
+    for la in (0,4,8,20,32,48):
         v=[]
         for f in sorted(glob.glob("gpurun_out/r06_lookahead/%s_la%d_r*.json"%(kind,la))):
             try:

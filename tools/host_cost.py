@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 
 
 def case(name, geometry_only=False, **opt):
-    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, lookahead=int(os.environ.get("LA", "4")), **opt)
+    m = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1, lookahead=int(os.environ.get("LA", "48")), **opt)
     assert m.prepare(wl.IDENTITY_PLANE, cam, poses[:20])
     m.reserve_tiles(3000 // max(1, opt.get("shard_count", 1)) + 400)
     feed = (lambda p: m.feed(None, p)) if geometry_only else (lambda p: m.feed_device(fr.data_ptr(), 3000, 4000, p))
