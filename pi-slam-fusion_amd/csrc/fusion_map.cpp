@@ -738,14 +738,16 @@ bool FusionMap::render_frame(const QueuedFrame& f)
         }
         std::swap(lat_, p.lat);
     }
-    // a keyframe that cannot take part (no cull for it, a sharded / single-band / per-level map) is rendered at once, and everything before it
+    // a keyframe that cannot take part (no cull for it: an untame homography, a per-level or per-op map, the cull switched off) is rendered at
+    // once, and everything that waits before it; a failure of one of THOSE renders is reported by this call
     while (pending_.size() > keep)
         if (!render_front()) return false;
     return true;
 }
 
-// The weight bounds of an admitted keyframe (build_tile_table will find them again when it is rendered: wlb only ever rises).
-// Creates the canvas' tiles, as Apply's tile loop does (.cpp:478-492).
+// The weight bounds of an admitted keyframe go into its tiles' wlb (which only ever rises; build_tile_table does not work them out again).
+// Creates the canvas' tiles, as Apply's tile loop does (.cpp:478-492), and remembers them for the render.  A keyframe never culls
+// itself by this: the largest weight it can have in a cell is not below the smallest (cell_out's margins only widen the gap).
 void FusionMap::pre_raise(FrameWork& w, std::vector<Tile*>& tiles)
 {
     tiles.assign((size_t)w.tx * w.ty, nullptr);
@@ -995,7 +997,8 @@ bool FusionMap::build_tile_table(const QueuedFrame& f, FrameWork& w)
                 unsigned out = 0;                                  // 64 x 64 cells in which this keyframe cannot win (bit 4 * row + column)
                 if (cull) {
                     // the whole tile first, against the smallest of its cells' bounds: out there is out in every cell (the tile's dilated
-                    // rectangle holds each cell's) -- most culled cells lie in such tiles, and only their wmin is still worked out
+                    // rectangle holds each cell's) -- most culled cells lie in such tiles; without lookahead their wmin is still worked out
+                    // cell by cell, with it the bounds went into wlb when the keyframe was admitted (pre_raise) and the cells are skipped
                     // A FRESH tile (no keyframe has written it: its first one copies unconditionally, .cpp:498) is rendered whole or not at
                     // all: its slot holds no weights a select could be run against, so no single cell may be left out.  It can be left out
                     // whole only through the lookahead -- its wlb then holds bounds of keyframes that wait behind this one; the one whose
