@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: level-0 block rows nothing rendered depends on are not launched (LevelArgs::row_gap) -- A/B in the experiments library, interleaved
+# (the switch PF_NO_ROW_GAP lived in the change this script measured; the change was reverted -- profiles/r06_ab.md (e))
 out=gpurun_out/r06_row_gap; mkdir -p $out
 export PF_LIB=pi-slam-fusion_amd/libpifusion_exp.so
 for rep in 1 2 3; do
