@@ -109,8 +109,8 @@ int     pf_debug_phase_stamps(unsigned long long* out, int cap_blocks);
 int     pf_debug_select_counts(unsigned long long* out, int reset);
 /* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
 unsigned pf_queue_size(pf_map* m);
-/* drain the feed queue and the device stream (no reference counterpart:
- * the reference is synchronous on the CPU)                                 */
+/* drain the feed queue, render the keyframes that wait for the cull's lookahead (pf_options.lookahead) and wait for the
+ * device stream (no reference counterpart: the reference is synchronous on the CPU).  Returns 0 if a render failed.       */
 int     pf_sync(pf_map* m);
 /* Map2D::save(filename), MultiBandMap2DCPU.cpp:779-847.  Writes PNG (.png),
  * else binary PPM.                                                         */

@@ -34,6 +34,9 @@ def test_options_keys_follow_svar_names(pf):
     assert L.pf_options_set(ctypes.byref(o), b"Map2D.Scale", b"0.5") == 1 and o.scale == 0.5
     assert L.pf_options_set(ctypes.byref(o), b"MultiBandMap2DCPU.ForceFloat", b"1") == 1 and o.force_float == 1
     assert L.pf_options_set(ctypes.byref(o), b"No.Such.Key", b"1") == 0
+    # the last field of pf_options (round 6): the binding's struct and the library's agree on its place and default
+    assert o.lookahead == 48 and o.fused == 1 and o.max_queue == 20
+    assert L.pf_options_set(ctypes.byref(o), b"Lookahead", b"0") == 1 and o.lookahead == 0 and o.fused == 1
 
 
 def test_no_device_fails_loudly(pf):
