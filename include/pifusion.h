@@ -95,7 +95,9 @@ int     pf_prepare(pf_map* m, const double plane[7], const double cam[6],
  * cv::Mat instead).                                                          */
 int     pf_feed(pf_map* m, const pf_image* img, const double pose[7]);
 /* Same, frame already resident in HBM (img->data is a device pointer that
- * must stay valid until pf_sync).  thread=0 maps only.                     */
+ * must stay valid -- and unchanged -- until pf_sync: the frame is read when its keyframe is rendered, which with
+ * pf_options.lookahead = n may be n feeds later; a caller that cycles through a ring of device buffers without
+ * pf_sync needs more than n + 1 of them, or sets lookahead to 0).  thread=0 maps only.                          */
 int     pf_feed_device(pf_map* m, const pf_image* img, const double pose[7]);
 /* Test hook (no reference counterpart): the bytes of the host frame most recently copied by pf_feed / pf_prepare,
  * read back from HBM -- (rows-1)*step + cols*channels of them.  Returns the byte count (out may be NULL to query it),

@@ -168,3 +168,31 @@ def test_seven_bands_weight_type_1_with_lookahead(pf, orc):
     assert g.sync() and compare_maps(g, o) == []
     assert g.culled_tiles() + g.culled_cells() > 0
     g.close()
+
+
+def test_full_size_sortie_with_a_deep_window_against_the_oracle(pf, orc):
+    """bench.py's path at its own size: thirty device-resident 4000 x 3000 keyframes over three flight lines, the default lookahead (48: every keyframe of a
+    line waits until the next line's are in), a reader in the middle of the second line; every tile level, two blends and the save against the oracle."""
+    torch = pytest.importorskip("torch")
+    wl = workloads()
+    cam = [4000, 3000, 3000, 3000, 2000, 1500]
+    poses = wl.serpentine(cam, 100.0, 30, per_row=10)
+    host = [wl.noise_frame(3000, 4000, 160 + k) if k else wl.smooth_frame(3000, 4000, 3) for k in range(3)]
+    dev = [torch.from_numpy(f).cuda() for f in host]
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=1)
+    o = orc.OracleMap(force_float=1)
+    assert g.prepare(wl.IDENTITY_PLANE, cam, poses) and o.prepare(wl.IDENTITY_PLANE, cam, poses)
+    for k, p in enumerate(poses):
+        assert g.feed_device(dev[k % 3].data_ptr(), 3000, 4000, p) and o.feed(host[k % 3], p)
+        if k == 14:
+            assert g.stats()["rendered"] == 15 and sorted(g.tiles()) == sorted(o.tiles())
+    assert g.sync() and g.grid() == o.grid()
+    assert compare_maps(g, o) == []
+    tiles = o.tiles()
+    have = set(tiles)
+    inner = [t for t in tiles if all((t[0] + dx, t[1] + dy) in have for dx in (-1, 0, 1) for dy in (-1, 0, 1))]
+    assert len(tiles) > 700 and g.culled_tiles() > 2000
+    for t in [inner[len(inner) // 4], inner[3 * len(inner) // 4]]:
+        assert np.array_equal(g.blend_tile(*t), o.blend_tile(*t)), t
+    assert np.array_equal(g.save_to_memory()[0], o.save()[0])
+    g.close()
