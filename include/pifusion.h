@@ -109,7 +109,8 @@ int     pf_debug_phase_stamps(unsigned long long* out, int cap_blocks);
 /* PF_STAMP=1 builds only: per pyramid level, pixels the max-weight select looked at (out[2*level]) and pixels that won
  * (out[2*level+1]) since the last reset; out holds 18 values.  Counts the useful tile bytes of a launch. */
 int     pf_debug_select_counts(unsigned long long* out, int reset);
-/* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113 */
+/* Map2D::queueSize(), MultiBandMap2DCPU.h:110-113: frames in the feed queue (cap 20, drop-oldest).  Keyframes the render thread has
+ * taken out of it and holds for the cull's lookahead are not counted: they no longer occupy a place in the queue and cannot be dropped. */
 unsigned pf_queue_size(pf_map* m);
 /* drain the feed queue, render the keyframes that wait for the cull's lookahead (pf_options.lookahead) and wait for the
  * device stream (no reference counterpart: the reference is synchronous on the CPU).  Returns 0 if a render failed.       */
