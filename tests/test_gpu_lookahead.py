@@ -196,3 +196,20 @@ def test_full_size_sortie_with_a_deep_window_against_the_oracle(pf, orc):
         assert np.array_equal(g.blend_tile(*t), o.blend_tile(*t)), t
     assert np.array_equal(g.save_to_memory()[0], o.save()[0])
     g.close()
+
+
+@pytest.mark.parametrize("force_float", [0, 1])
+def test_equal_weights_the_newest_keyframe_wins(pf, orc, force_float):
+    """every pose twice in a row, and the first three again at the end, each time with other pixels: the two keyframes' weights are EQUAL everywhere, `>=`
+    (.cpp:521, :542) lets the newer one win, and no bound of one may cull the other (ub >= lb of the same geometry)"""
+    wl = workloads()
+    base = sortie(wl, 71, n=9, yaw=15.0, tilt=4.0)
+    poses = [p for q in base for p in (q, list(q))] + [list(p) for p in base[:3]]
+    g = pf.Map2D.create(pf.TypeMultiBandCPU, False, force_float=force_float, scale=2.0, lookahead=7)
+    o = orc.OracleMap(force_float=force_float, scale=2.0)
+    assert g.prepare(wl.IDENTITY_PLANE, CAM, base[:8]) == o.prepare(wl.IDENTITY_PLANE, CAM, base[:8])
+    for k, p in enumerate(poses):
+        img = frame(wl, 71, k)
+        assert g.feed(img, p) == o.feed(img, p)
+    assert g.sync() and compare_maps(g, o) == []
+    g.close()
