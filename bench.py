@@ -403,6 +403,8 @@ def timed_run(m, run, W, K, event_every, barrier):
     gc.collect()
     gc.disable()
     barrier()
+    # The map is drained here (m.sync() above rendered every warm-up keyframe) and again before t1 (m.sync() below renders what the cull's
+    # lookahead still holds): all K timed keyframes, and only they, are rendered between t0 and t1.
     t0 = time.perf_counter()
     run(W, W + K)
     m.sync()
