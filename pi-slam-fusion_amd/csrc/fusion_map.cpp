@@ -727,7 +727,16 @@ bool FusionMap::render_frame(const QueuedFrame& f)
     size_t keep = 0;
     if (w.cull) {
         if (lat_.sx.capacity() == 0 && !lat_pool_.empty()) { lat_ = std::move(lat_pool_.back()); lat_pool_.pop_back(); }
-        cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << w.L) - 2 + 63) / 64);
+        // a shard that owns a quarter of the canvas' tiles or more has the whole lattice mapped at once, like an unsharded map (one tile_owner
+        // call per tile: ~1 us); below that the points are mapped as its tiles ask for them
+        bool map_all = opt_.shard_count <= 1;
+        if (!map_all) {
+            int mine = 0;
+            for (int y = 0; y < w.ty; y++)
+                for (int x = 0; x < w.tx; x++) mine += tile_owner(opt_.shard_count, opt_.shard_block, w.xminInt + x + off_x_, w.yminInt + y + off_y_) == opt_.shard_rank;
+            map_all = 4 * mine >= w.tx * w.ty;
+        }
+        cull_lattice(w.Minv, w.crows, w.ccols, f.cols, f.rows, single_band_ ? 0 : ((2 << w.L) - 2 + 63) / 64, map_all);
         if (lookahead_ok()) {
             // the keyframe's own lower bounds enter the tiles' wlb NOW: the keyframes ahead of it in the queue are decided against them
             if (!tiles_pool_.empty()) { p.tiles = std::move(tiles_pool_.back()); tiles_pool_.pop_back(); }
@@ -754,8 +763,8 @@ void FusionMap::pre_raise(FrameWork& w, std::vector<Tile*>& tiles)
 
     const int S = cull_sub_, span = 4 / S;
     const bool sharded = opt_.shard_count > 1;
-    if (!sharded && S == 4) {
-        // Unsharded: every lattice point is mapped (cull_lattice), every cell is asked.  The same arithmetic as cell_out's first half, without
+    if (lat_.all && S == 4) {
+        // Every lattice point is mapped (cull_lattice), every cell of an owned tile is asked.  The same arithmetic as cell_out's first half, without
         // its calls: the farthest corner of a cell's dilated square from a pass that pairs the points e steps apart along a row first.
         const int nx = lat_.nx, ny = lat_.ny, e = 1 + 2 * lat_.dil;
         pair_d_.resize((size_t)nx * ny); pair_in_.resize((size_t)nx * ny);
@@ -768,7 +777,9 @@ void FusionMap::pre_raise(FrameWork& w, std::vector<Tile*>& tiles)
         const int wt = opt_.weight_type;
         for (int y = 0; y < w.ty; y++)
             for (int x = 0; x < w.tx; x++) {
-                Tile* t = store_.get_or_create(w.xminInt + x + off_x_, w.yminInt + y + off_y_);
+                const int sx = w.xminInt + x + off_x_, sy = w.yminInt + y + off_y_;
+                if (sharded && tile_owner(opt_.shard_count, opt_.shard_block, sx, sy) != opt_.shard_rank) continue;
+                Tile* t = store_.get_or_create(sx, sy);
                 if (!t) { tiles.clear(); return; }
                 tiles[(size_t)y * w.tx + x] = t;
                 for (int qy = 0; qy < 4; qy++) {
@@ -1559,8 +1570,9 @@ bool FusionMap::cull_frame_ok(const double M[9], int crows, int ccols) const
 // The canvas lattice (64 (k - dil), 64 (m - dil)), k = 0 .. ccols / 64 + 2 dil, mapped into the source frame: position, squared distance
 // from the image centre, inside-the-frame flag.  A cell's dilated rectangle has its corners on it.  Points are mapped on first use
 // (a shard asks for an eighth of them); one division per point, no square root.
-void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil)
+void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil, bool map_all)
 {
+    lat_.all = map_all;
     lat_.dil = dil;                                             // dilation of a cell in lattice steps of 64 pixels
     lat_.nx = ccols / 64 + 2 * dil + 1; lat_.ny = crows / 64 + 2 * dil + 1;
     const size_t n = (size_t)lat_.nx * lat_.ny;
@@ -1569,8 +1581,9 @@ void FusionMap::cull_lattice(const double M[9], int crows, int ccols, int cols, 
     lat_.inv_dis_max = 1.0 / lat_.dis_max;
     lat_.cols = cols; lat_.rows = rows;
     for (int i = 0; i < 9; i++) lat_.M[i] = M[i];
-    if (opt_.shard_count > 1) return;                           // a shard asks for a fraction of the points: on first use
-    // unsharded, every point is needed (a cell's dilated rectangle has its corners on neighbouring points): all of them now, row by row,
+    if (!map_all) return;                                       // a shard that owns a small part of the canvas asks for a fraction of the points: on first use
+    // unsharded (or a shard that owns most of this canvas: the replicas of bench.py's weak mode own all of it), every point is needed (a cell's
+    // dilated rectangle has its corners on neighbouring points): all of them now, row by row,
     // in loops without branches that the compiler turns into packed divisions (a third of the time of mapping them one by one)
     const double xc = lat_.xc, yc = lat_.yc, cmax = cols - 2.0, rmax = rows - 2.0;
     for (int m = 0; m < lat_.ny; m++) {

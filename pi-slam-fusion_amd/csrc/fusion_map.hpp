@@ -133,7 +133,7 @@ public:
     // the cull of render_frame (tiles in which a keyframe cannot win the select): see there
     bool cull_frame_ok(const double M[9], int crows, int ccols) const;
     // source positions of the canvas lattice points (-64 + 64 k, -64 + 64 m) the cells' dilated rectangles have their corners on
-    void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil);
+    void cull_lattice(const double M[9], int crows, int ccols, int cols, int rows, int dil, bool map_all);
     size_t lattice_point(int k, int m);
     bool cell_out(int k, int m, int span, int weight_type, float wlb, bool want_out, float* wmin);
     long long culled_tiles() { std::lock_guard<std::mutex> l(mu_); (void)drain(); return n_culled_tiles_; }
@@ -216,7 +216,7 @@ private:
     double cull_margin_px_ = exp_env_double("PF_CULL_MARGIN_PX", 2.0);
     double cull_margin_w_ = exp_env_double("PF_CULL_MARGIN_W", 1e-5);
     int cull_sub_ = exp_env_int("PF_CULL_SUB", 4) == 2 ? 2 : 4;      // cells per tile edge (experiments library: 2 = quadrants)
-    struct Lattice { int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; };
+    struct Lattice { bool all = false; int nx = 0, ny = 0, dil = 1, cols = 0, rows = 0; double xc = 0, yc = 0, dis_max = 1, inv_dis_max = 1, M[9] = {}; std::vector<double> sx, sy, d; std::vector<unsigned char> in; };
     Lattice lat_;                                   // of the keyframe being admitted / rendered
     Camera cam_{};
     double ele_size_ = 0, ele_size_inv_ = 0, length_pixel_ = 0, length_pixel_inv_ = 0;

@@ -53,4 +53,7 @@ print("PF_ABLATE =", os.environ.get("PF_ABLATE"))
 case("unsharded, device frames")
 case("rank 0 of 8, cell 8 tiles", shard_rank=0, shard_count=8, shard_block=8)
 case("rank 0 of 8, cell 2 tiles", shard_rank=0, shard_count=8, shard_block=2)
+# bench.py's weak mode: a rank of 8 whose 128-tile hash cell holds the whole sortie -- it owns every tile of every canvas
+own = pf.tile_owner(pf.default_options(shard_count=8, shard_block=128), 5, 5)
+case("rank of 8 that owns the whole sortie (cell 128 tiles)", shard_rank=own, shard_count=8, shard_block=128)
 case("geometry-only feeds", geometry_only=True)
